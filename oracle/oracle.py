@@ -1,0 +1,156 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  See oracle/stencil_oracle.h for what is restated and how it is
+pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+HOTSPOT_CELL = np.dtype([("temp", "<f4"), ("power", "<f4")])
+SELFCHECK_CELL = np.dtype(
+    [("r", "<i4"), ("c", "<i4"), ("i_iteration", "<i4"), ("i_subiteration", "<i4"), ("status", "<i4")]
+)
+FDTD_CELL = np.dtype([(n, "<f4") for n in ("ex", "ey", "hz", "hz_sum", "ca", "cb", "da", "db")])
+
+JACOBI_VARIANTS = {
+    "Jacobi1General": 0,
+    "Jacobi2Constant": 1,
+    "Jacobi3Constant": 2,
+    "Jacobi4Constant": 3,
+    "Jacobi5Constant": 4,
+    "Jacobi4General": 5,
+    "Jacobi5General": 6,
+    "Jacobi9General": 7,
+}
+
+
+class HotspotParams(C.Structure):
+    _fields_ = [("Rx_1", C.c_float), ("Ry_1", C.c_float), ("Rz_1", C.c_float), ("Cap_1", C.c_float)]
+
+
+class FdtdParams(C.Structure):
+    _fields_ = [
+        ("dt", C.c_float),
+        ("t_0", C.c_float),
+        ("tau", C.c_float),
+        ("omega", C.c_float),
+        ("cutoff_iteration", C.c_uint64),
+        ("detect_iteration", C.c_uint64),
+        ("source_radius_squared", C.c_float),
+        ("source_r", C.c_float),
+        ("source_c", C.c_float),
+        ("source_distance_bound", C.c_float),
+        ("double_center_rc", C.c_float),
+    ]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.oracle_fdtd_tdv.restype = C.c_float
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _sz(x):
+    return C.c_size_t(int(x))
+
+
+def jacobi(variant, coef, grid, n_iterations, halo=0.0, iteration_offset=0, n_threads=1):
+    v = JACOBI_VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    src = np.ascontiguousarray(grid, dtype=np.float32)
+    out = np.empty_like(src)
+    cf = np.zeros(9, dtype=np.float32)
+    cf[: len(coef)] = np.asarray(coef, dtype=np.float32)
+    rc = lib().oracle_jacobi(
+        C.c_int(v), _p(cf), _p(src), _p(out), _sz(src.shape[0]), _sz(src.shape[1]),
+        C.c_float(halo), _sz(iteration_offset), _sz(n_iterations), C.c_int(n_threads),
+    )
+    assert rc == 0
+    return out
+
+
+def jacobi_init(H, W):
+    g = np.empty((H, W), dtype=np.float32)
+    lib().oracle_jacobi_init(_p(g), _sz(H), _sz(W))
+    return g
+
+
+def hotspot_params(n_rows, n_columns):
+    p = HotspotParams()
+    lib().oracle_hotspot_params_for_grid(_sz(n_rows), _sz(n_columns), C.byref(p))
+    return p
+
+
+def hotspot(params, cells, n_iterations, iteration_offset=0, n_threads=1):
+    src = np.ascontiguousarray(cells, dtype=HOTSPOT_CELL)
+    out = np.empty_like(src)
+    rc = lib().oracle_hotspot(
+        C.byref(params), _p(src), _p(out), _sz(src.shape[0]), _sz(src.shape[1]),
+        _sz(iteration_offset), _sz(n_iterations), C.c_int(n_threads),
+    )
+    assert rc == 0
+    return out
+
+
+def conway(grid, n_iterations, n_threads=1):
+    src = np.ascontiguousarray(grid, dtype=np.uint8)
+    out = np.empty_like(src)
+    rc = lib().oracle_conway(
+        _p(src), _p(out), _sz(src.shape[0]), _sz(src.shape[1]), _sz(n_iterations), C.c_int(n_threads)
+    )
+    assert rc == 0
+    return out
+
+
+def selfcheck(radius, cells, iteration_offset, n_iterations, n_threads=1):
+    src = np.ascontiguousarray(cells, dtype=SELFCHECK_CELL)
+    out = np.empty_like(src)
+    rc = lib().oracle_selfcheck(
+        _sz(radius), _p(src), _p(out), _sz(src.shape[0]), _sz(src.shape[1]),
+        _sz(iteration_offset), _sz(n_iterations), C.c_int(n_threads),
+    )
+    assert rc == 0
+    return out
+
+
+def selfcheck_input(H, W, iteration_offset):
+    """tests/StencilUpdateTest.hpp:37-45"""
+    g = np.zeros((H, W), dtype=SELFCHECK_CELL)
+    g["r"] = np.arange(H, dtype=np.int32)[:, None]
+    g["c"] = np.arange(W, dtype=np.int32)[None, :]
+    g["i_iteration"] = iteration_offset
+    return g
+
+
+def fdtd_tdv(params, iteration):
+    return float(lib().oracle_fdtd_tdv(C.byref(params), _sz(iteration)))
+
+
+def fdtd(params, cells, n_iterations, iteration_offset=0, n_threads=1):
+    src = np.ascontiguousarray(cells, dtype=FDTD_CELL)
+    out = np.empty_like(src)
+    rc = lib().oracle_fdtd(
+        C.byref(params), _p(src), _p(out), _sz(src.shape[0]), _sz(src.shape[1]),
+        _sz(iteration_offset), _sz(n_iterations), C.c_int(n_threads),
+    )
+    assert rc == 0
+    return out
