@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Jacobi 5-point (Jacobi5General) fp32 on a synthetic 16384 x 16384 grid.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  A "step" is one StencilUpdate call of
+`--generations` generations (default 100, so the default 10 steps are BASELINE.json's 1000
+generations).  Rank 0 prints ONE JSON line.
+
+Metric: Gcell-updates/s = H*W*generations / time (sub-iterations not counted), the reference's
+definition (scripts/benchmark-common.jl:97-98,122).  The grid is resident in HBM before the timed
+region starts.  N > 1: the 16384*N/... see DESIGN.md -- weak scaling over row strips: every rank
+owns a 16384-row strip of a (16384*N) x 16384 grid and exchanges ghost rows with its neighbours
+over RCCL once per launch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md, chip-level parameters)
+BYTES_PER_CELL_UPDATE = 8  # 2 * sizeof(float) * n_subiterations (scripts/benchmark-common.jl:150-151)
+COEF = [0.2, 0.2, 0.2, 0.2, 0.2]  # examples/jacobi/scripts/benchmark.jl:44-45
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=16384, help="grid rows (per GPU) and columns")
+    ap.add_argument("--generations", type=int, default=100, help="generations per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=4096)
+    ap.add_argument("--cpu-generations", type=int, default=4)
+    return ap.parse_args()
+
+
+def init_grid_device(torch, rows, cols, row0, total_rows, device):
+    """Centred-square init of examples/jacobi/jacobi.cpp:114-122, generated on the device."""
+    r = torch.arange(row0, row0 + rows, device=device, dtype=torch.float64)[:, None]
+    c = torch.arange(cols, device=device, dtype=torch.float64)[None, :]
+    inside = (r >= total_rows * 0.25) & (r < total_rows * 0.75) & (c >= cols * 0.25) & (c < cols * 0.75)
+    return inside.to(torch.float32).contiguous()
+
+
+def cpu_baseline(size, generations):
+    """The oracle (a port of the reference's cpu backend) on the host cores, bounded sample."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    cores = os.cpu_count() or 1
+    grid = O.jacobi_init(size, size)
+    O.jacobi("Jacobi5General", COEF, grid[:64, :64].copy(), 1, n_threads=cores)  # warm the pool
+    t0 = time.perf_counter()
+    O.jacobi("Jacobi5General", COEF, grid, generations, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": size * size * generations / dt / 1e9,
+        "unit": "Gcell-updates/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"Jacobi5General {size}x{size}, {generations} generations, OpenMP over rows, {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    from stencilstream_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    capi.init(local_rank)
+    stream = torch.cuda.current_stream(device)
+
+    H, W, gens = args.size, args.size, args.generations
+    p = capi.JacobiParams()
+    for i, c in enumerate(COEF):
+        p.coef[i] = c
+    halo = np.float32(0.0).tobytes()
+    info = capi.app_info("jacobi5general")
+
+    if world == 1:
+        src = init_grid_device(torch, H, W, 0, H, device)
+        dst = torch.empty_like(src)
+        dom = capi.Domain(H, W, 0, H, W)
+
+        def step():
+            return capi.app_run("jacobi5general", p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens,
+                                blocking=False, profiling=False, stream=stream.cuda_stream)
+
+        barrier = lambda: None
+        total_rows = H
+    else:
+        import torch.distributed as dist
+
+        from stencilstream_amd.dist import StripDomain
+
+        dist.init_process_group("nccl", device_id=device)
+        total_rows = H * world
+        strip = StripDomain("jacobi5general", p, halo, total_rows, W, rank, world, device, np.dtype("<f4"))
+        strip.load_owned(init_grid_device(torch, H, W, rank * H, total_rows, device))
+
+        def step():
+            strip.advance(0, gens)
+
+        barrier = dist.barrier
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    launches = 0
+    for _ in range(args.steps):
+        r = step()
+        launches += r.n_launches if r is not None else 0
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        cells = total_rows * W * gens * args.steps
+        value = cells / elapsed / 1e9
+        out = {
+            "metric": "Gcell-updates/s, Jacobi-5pt fp32 16384^2",
+            "value": value,
+            "unit": "Gcell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Jacobi5General fp32 {total_rows}x{W}, {gens} generations per step, halo 0, coef 5x0.2",
+                "generations_total": gens * args.steps,
+                "temporal_blocking": int(info.max_generations),
+                "decomposition": "none" if world == 1 else f"{world} row strips of {H} rows, RCCL ghost rows",
+            },
+        }
+        if world == 1:
+            # the dominant (only) kernel: per launch it advances H*W cells by T generations
+            kernel_ms = ev0.elapsed_time(ev1) / max(launches, 1)
+            T = gens * args.steps / max(launches, 1)
+            alg_bytes = H * W * BYTES_PER_CELL_UPDATE * T
+            achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "sweep_kernel<Jacobi5General>",
+                "kernel_ms": kernel_ms,
+                "generations_per_launch": T,
+                "algorithmic_bytes_per_launch": alg_bytes,
+            }
+            traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
+            if os.path.exists(traffic_file):
+                try:
+                    out["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_generations)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

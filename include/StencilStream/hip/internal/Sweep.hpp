@@ -1,0 +1,550 @@
+// The generation sweep of the MI355X backend: a register-resident temporal pipeline per wavefront.
+//
+// What it replaces: the one-work-item-per-cell SYCL kernels of the reference,
+// StencilStream/cuda/StencilUpdate.hpp:227-263 (AoS) and :346-396 (SoA), launched once per
+// (iteration, sub-iteration).  Semantics reproduced exactly: every
+// out-of-grid neighbour reads Params::halo_value in every sub-step, stencil.id / iteration /
+// subiteration / grid_range / time_dependent_value are exact per sub-step, the source grid is
+// never written.
+//
+// How it maps to CDNA4 instead:
+//  * One 64-lane wavefront owns a column strip of 64*K cells and streams down the rows of a row
+//    chunk.  Lane i holds K adjacent cells of the current row of every pipeline level in VGPRs.
+//  * T generations x n_subiterations sub-steps = S pipeline levels live in registers at once
+//    (the FPGA design's chain of processing elements, folded into one wave).  Feeding input row y
+//    makes level l emit row y - l*r; each level keeps its last 2r rows as a rotating register
+//    window, so a cell travels HBM -> registers once and comes back S sub-steps later.
+//  * North/south neighbours are the lane's own registers; west/east neighbours of a lane's edge
+//    cells come from the adjacent lanes by DPP wave shifts (v_mov_b32_dpp wave_shr/wave_shl), no LDS.
+//  * Strips overlap by the halo depth G = r*S on each side (redundant compute instead of
+//    inter-wave synchronisation); chunks overlap by G rows for pipeline warm-up.
+//  * HBM rows are read as one K-wide vector per lane (1 KiB per wave and row for fp32, K = 4),
+//    software-prefetched P rows ahead, and written the same way.
+#pragma once
+#include "../../Concepts.hpp"
+#include "../../Stencil.hpp"
+#include "Runtime.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <tuple>
+#include <type_traits>
+
+namespace stencil {
+namespace hip {
+namespace internal {
+
+using stencil::internal::round_up;
+using stencil::internal::static_for;
+
+constexpr int wave_size = 64;
+
+// ------------------------------------------------------------------ cell layout
+// A cell type opts into per-field planes with `static constexpr auto fields = std::make_tuple(
+// &Cell::a, ...)` (protocol of StencilStream/cuda/internal/Helpers.hpp:37-45).
+template <typename Cell>
+concept SplittableCell = requires {
+    std::tuple_size<std::remove_cvref_t<decltype(Cell::fields)>>::value;
+};
+
+template <typename Cell> constexpr int field_count() {
+    if constexpr (SplittableCell<Cell>)
+        return int(std::tuple_size_v<std::remove_cvref_t<decltype(Cell::fields)>>);
+    else
+        return 1;
+}
+
+template <typename Cell, int I>
+using FieldType =
+    std::remove_reference_t<decltype(std::declval<Cell &>().*std::get<I>(Cell::fields))>;
+
+// Member pointer of field I as a compile-time value (never a load from the tuple object, so the
+// accesses below stay static and the cells stay in registers).
+template <typename Cell, int I> constexpr auto field_pointer() {
+    constexpr auto pointer = std::get<I>(Cell::fields);
+    return pointer;
+}
+
+template <typename Cell, int I> inline std::size_t field_offset() {
+    Cell probe{};
+    return std::size_t(reinterpret_cast<const char *>(&(probe.*field_pointer<Cell, I>())) -
+                       reinterpret_cast<const char *>(&probe));
+}
+
+constexpr int max_planes = 16;
+
+// Device pointers of one grid: a single AoS plane of cells, or one dense plane per field.
+template <typename Cell, bool SOA> struct PlaneSet;
+
+template <typename Cell> struct PlaneSet<Cell, false> {
+    static constexpr int n_planes = 1;
+    void *plane[1];
+
+    static std::size_t elem_size(int) { return sizeof(Cell); }
+    static std::size_t elem_offset(int) { return 0; }
+
+    template <int K> STST_DEVICE void load(std::size_t first, Cell (&cells)[K]) const {
+        __builtin_memcpy(cells, static_cast<const Cell *>(plane[0]) + first, K * sizeof(Cell));
+    }
+    STST_DEVICE void load_one(std::size_t at, Cell &cell) const {
+        cell = static_cast<const Cell *>(plane[0])[at];
+    }
+    template <int K> STST_DEVICE void store(std::size_t first, Cell const (&cells)[K]) const {
+        __builtin_memcpy(static_cast<Cell *>(plane[0]) + first, cells, K * sizeof(Cell));
+    }
+    STST_DEVICE void store_one(std::size_t at, Cell const &cell) const {
+        static_cast<Cell *>(plane[0])[at] = cell;
+    }
+};
+
+template <typename Cell> struct PlaneSet<Cell, true> {
+    static_assert(SplittableCell<Cell>, "split_cell_structure needs Cell::fields");
+    static constexpr int n_planes = field_count<Cell>();
+    static_assert(n_planes <= max_planes);
+    void *plane[n_planes];
+
+    static std::size_t elem_size(int i) {
+        std::size_t sizes[n_planes];
+        static_for<0, n_planes>([&](auto f) { sizes[f] = sizeof(FieldType<Cell, f>); });
+        return sizes[i];
+    }
+    static std::size_t elem_offset(int i) {
+        std::size_t offsets[n_planes];
+        static_for<0, n_planes>([&](auto f) { offsets[f] = field_offset<Cell, f>(); });
+        return offsets[i];
+    }
+
+    template <int K> STST_DEVICE void load(std::size_t first, Cell (&cells)[K]) const {
+        static_for<0, n_planes>([&](auto f) __attribute__((always_inline)) {
+            using E = FieldType<Cell, f>;
+            constexpr auto member = field_pointer<Cell, f>();
+            E values[K];
+            __builtin_memcpy(values, static_cast<const E *>(plane[f]) + first, K * sizeof(E));
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                cells[k].*member = values[k];
+        });
+    }
+    STST_DEVICE void load_one(std::size_t at, Cell &cell) const {
+        static_for<0, n_planes>([&](auto f) __attribute__((always_inline)) {
+            using E = FieldType<Cell, f>;
+            constexpr auto member = field_pointer<Cell, f>();
+            cell.*member = static_cast<const E *>(plane[f])[at];
+        });
+    }
+    template <int K> STST_DEVICE void store(std::size_t first, Cell const (&cells)[K]) const {
+        static_for<0, n_planes>([&](auto f) __attribute__((always_inline)) {
+            using E = FieldType<Cell, f>;
+            constexpr auto member = field_pointer<Cell, f>();
+            E values[K];
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                values[k] = static_cast<E>(cells[k].*member);
+            __builtin_memcpy(static_cast<E *>(plane[f]) + first, values, K * sizeof(E));
+        });
+    }
+    STST_DEVICE void store_one(std::size_t at, Cell const &cell) const {
+        static_for<0, n_planes>([&](auto f) __attribute__((always_inline)) {
+            using E = FieldType<Cell, f>;
+            constexpr auto member = field_pointer<Cell, f>();
+            static_cast<E *>(plane[f])[at] = static_cast<E>(cell.*member);
+        });
+    }
+};
+
+// ------------------------------------------------------------------ lane exchange
+// Value held by the neighbouring lane, moved with DPP wave shifts (full 64-lane shift on gfx9-family
+// ISAs).  Works on the 32-bit words of any trivially copyable T.
+template <int DppCtrl, typename T> STST_DEVICE inline T lane_shift(T const &value) {
+    static_assert(std::is_trivially_copyable_v<T>);
+    constexpr int n_words = int((sizeof(T) + 3) / 4);
+    struct Words {
+        int w[n_words];
+    } words = {};
+    __builtin_memcpy(&words, &value, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < n_words; i++)
+        words.w[i] = __builtin_amdgcn_update_dpp(0, words.w[i], DppCtrl, 0xf, 0xf, false);
+    T shifted;
+    __builtin_memcpy(&shifted, &words, sizeof(T));
+    return shifted;
+}
+// value of lane-1 (data moves towards higher lanes): DPP wave_shr:1
+template <typename T> STST_DEVICE inline T from_west_lane(T const &v) { return lane_shift<0x138>(v); }
+// value of lane+1: DPP wave_shl:1
+template <typename T> STST_DEVICE inline T from_east_lane(T const &v) { return lane_shift<0x130>(v); }
+
+// ------------------------------------------------------------------ tuning
+constexpr int ceil_pow2(int v) {
+    int p = 1;
+    while (p < v)
+        p *= 2;
+    return p;
+}
+
+template <typename Cell, bool SOA> constexpr int cell_words() {
+    if constexpr (SOA) {
+        int words = 0;
+        static_for<0, field_count<Cell>()>(
+            [&](auto f) { words += int((sizeof(FieldType<Cell, f>) + 3) / 4); });
+        return words;
+    } else {
+        return int((sizeof(Cell) + 3) / 4);
+    }
+}
+
+} // namespace internal
+
+// Shape of the wave pipeline for a transition function.  Specialise for a concrete F to override:
+//   cells_per_lane (K)   adjacent cells per lane and row (vector width of the HBM accesses)
+//   max_generations (T)  deepest temporal blocking compiled (powers of two up to it are built)
+//   prefetch_rows (P)    rows loaded ahead; must be a multiple of 2*radius
+//   interior_variant     also build the check-free code path for waves away from the grid edge
+template <typename F, bool SOA> struct SweepTuning {
+  private:
+    static constexpr int R = int(F::stencil_radius);
+    static constexpr int NS = int(F::n_subiterations);
+    static constexpr int W = internal::cell_words<typename F::Cell, SOA>();
+    static constexpr int pick_k() {
+        int k = 4;
+        while (k > 1 && k / 2 >= R && 2 * R * k * W * NS > 64)
+            k /= 2;
+        return std::max(k, internal::ceil_pow2(R));
+    }
+    static constexpr int pick_t(int k) {
+        int t = 8;
+        while (t > 1 && (t * NS * 2 * R * k * W > 96 || 64 * k <= 2 * internal::round_up(R * t * NS, k)))
+            t /= 2;
+        return t;
+    }
+    static constexpr int pick_p(int k) {
+        int p = 2 * R;
+        if (k * W <= 8)
+            while (p < 4)
+                p += 2 * R;
+        return p;
+    }
+
+  public:
+    static constexpr int cells_per_lane = pick_k();
+    static constexpr int max_generations = pick_t(cells_per_lane);
+    static constexpr int prefetch_rows = pick_p(cells_per_lane);
+    static constexpr bool interior_variant = (W * NS <= 16);
+};
+
+namespace internal {
+
+// Geometry of one sweep launch, in global grid coordinates.
+struct SweepGeometry {
+    std::int32_t grid_h, grid_w;        // stencil.grid_range
+    std::int32_t row_origin;            // global row of buffer row 0
+    std::int32_t load_lo, load_hi;      // global rows present in the source buffers
+    std::int32_t out_begin, out_end;    // global rows to produce
+    std::int32_t chunk_rows;            // rows of output per wave
+    std::uint32_t n_strips, n_chunks;   // wave grid
+    std::uint64_t pitch;                // elements between rows
+    std::uint64_t iteration;            // generation index of the first level
+};
+
+template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> struct Sweep {
+    using Cell = typename F::Cell;
+    using TDV = typename F::TimeDependentValue;
+    using Planes = PlaneSet<Cell, SOA>;
+    using StencilImpl = Stencil<Cell, F::stencil_radius, TDV>;
+
+    static constexpr int R = int(F::stencil_radius);
+    static constexpr int NS = int(F::n_subiterations);
+    static constexpr int S = T * NS;            // pipeline levels
+    static constexpr int G = R * S;             // halo depth in cells (rows and columns)
+    static constexpr int GX = round_up(G, K);   // column halo rounded to whole lanes
+    static constexpr int LW = wave_size * K;    // columns a wave loads
+    static constexpr int OW = LW - 2 * GX;      // columns a wave produces
+    static constexpr int NWIN = 2 * R;          // rows each level keeps
+    static constexpr int D = 2 * R + 1;
+
+    static_assert(K >= R, "a lane must hold at least `radius` cells so neighbours are one lane away");
+    static_assert(OW >= K, "halo consumes the whole strip: lower max_generations or raise K");
+    static_assert(P % NWIN == 0, "prefetch depth must be a multiple of the window length");
+    static_assert(std::is_trivially_copyable_v<F> && std::is_trivially_copyable_v<Cell> &&
+                  std::is_trivially_copyable_v<TDV>);
+
+    struct Args {
+        F f;
+        Cell halo;
+        TDV tdv[T];
+        Planes src, dst;
+        SweepGeometry geo;
+    };
+
+    template <bool EDGE>
+    STST_DEVICE static void run(Args const &a, const int lane, const int strip, const int ya,
+                                const int yb) {
+        SweepGeometry const &g = a.geo;
+        const int x0 = strip * OW - GX + lane * K; // global column of the lane's first cell
+        const int ystart = ya - G;
+        const int y_load_end = yb + G < g.load_hi ? yb + G : g.load_hi;
+
+        bool col_in[K];
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            col_in[k] = unsigned(x0 + k) < unsigned(g.grid_w);
+        const bool vec_in = x0 >= 0 && x0 + K <= g.grid_w;
+        const bool lane_stores = lane * K >= GX && lane * K + K <= LW - GX;
+
+        Cell win[S][NWIN][K]; // level l-1's older rows, rotating
+        Cell pre[P][K];       // rows in flight from HBM
+        static_for<0, S>([&](auto l) __attribute__((always_inline)) {
+            static_for<0, NWIN>([&](auto s) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    win[l][s][k] = a.halo;
+            });
+        });
+        static_for<0, P>([&](auto u) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                pre[u][k] = a.halo;
+        });
+
+        auto load_row = [&](const int y, Cell(&into)[K]) __attribute__((always_inline)) {
+            if (y >= g.load_lo && y < y_load_end) { // wave-uniform
+                const std::size_t first =
+                    std::size_t(y - g.row_origin) * g.pitch + std::size_t(std::int64_t(x0));
+                if constexpr (!EDGE) {
+                    a.src.template load<K>(first, into);
+                } else {
+                    if (vec_in) {
+                        a.src.template load<K>(first, into);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; k++)
+                            if (col_in[k])
+                                a.src.load_one(first + k, into[k]);
+                    }
+                }
+            }
+        };
+
+        static_for<0, P>([&](auto u) __attribute__((always_inline)) { load_row(ystart + u, pre[u]); });
+
+        const int n_rows_in = yb - ya + 2 * G;
+        for (int it = 0; it < n_rows_in; it += P) {
+            static_for<0, P>([&](auto u) __attribute__((always_inline)) {
+                const int y = ystart + it + u;
+                Cell cur[K];
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    cur[k] = pre[u][k];
+                load_row(y + P, pre[u]);
+
+                if constexpr (EDGE) {
+                    const bool row_in = unsigned(y) < unsigned(g.grid_h);
+#pragma unroll
+                    for (int k = 0; k < K; k++)
+                        if (!(row_in && col_in[k]))
+                            cur[k] = a.halo;
+                }
+
+                static_for<0, S>([&](auto lc) __attribute__((always_inline)) {
+                    constexpr int level = lc + 1;           // level being computed
+                    constexpr int oldest = u % NWIN;        // window slot holding the oldest row
+                    const int j = y - level * R;            // global row this level emits now
+                    const std::size_t iteration = g.iteration + std::size_t((level - 1) / NS);
+                    const std::size_t subiteration = std::size_t((level - 1) % NS);
+                    TDV const &tdv = a.tdv[(level - 1) / NS];
+
+                    // rows j-R .. j+R of the previous level, widened by R cells from both neighbour lanes
+                    Cell ext[D][K + 2 * R];
+                    static_for<0, D>([&](auto rr) __attribute__((always_inline)) {
+                        Cell const(&row)[K] = [&]() -> Cell const(&)[K] {
+                            if constexpr (rr < NWIN)
+                                return win[lc][(oldest + rr) % NWIN];
+                            else
+                                return cur;
+                        }();
+#pragma unroll
+                        for (int k = 0; k < K; k++)
+                            ext[rr][R + k] = row[k];
+#pragma unroll
+                        for (int d = 1; d <= R; d++) {
+                            ext[rr][R - d] = from_west_lane(row[K - d]);
+                            ext[rr][R + K - 1 + d] = from_east_lane(row[d - 1]);
+                        }
+                    });
+
+                    Cell next[K];
+                    bool row_in = true;
+                    if constexpr (EDGE)
+                        row_in = unsigned(j) < unsigned(g.grid_h);
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        StencilImpl st(sycl::id<2>(std::size_t(std::int64_t(j)),
+                                                   std::size_t(std::int64_t(x0 + k))),
+                                       sycl::range<2>(std::size_t(g.grid_h), std::size_t(g.grid_w)),
+                                       iteration, subiteration, tdv);
+#pragma unroll
+                        for (int rr = 0; rr < D; rr++)
+#pragma unroll
+                            for (int cc = 0; cc < D; cc++)
+                                st[sycl::id<2>(rr, cc)] = ext[rr][k + cc];
+                        next[k] = a.f(st);
+                        if constexpr (EDGE)
+                            if (!(row_in && col_in[k]))
+                                next[k] = a.halo; // out-of-grid cells never evolve
+                    }
+
+                    // the newest row of the previous level replaces the oldest one in its window
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        win[lc][oldest][k] = cur[k];
+                        cur[k] = next[k];
+                    }
+                });
+
+                const int j = y - G; // row leaving the last level
+                if (j >= ya && j < yb && lane_stores) {
+                    const std::size_t first =
+                        std::size_t(j - g.row_origin) * g.pitch + std::size_t(std::int64_t(x0));
+                    if (!EDGE || vec_in) {
+                        a.dst.template store<K>(first, cur);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; k++)
+                            if (col_in[k])
+                                a.dst.store_one(first + k, cur[k]);
+                    }
+                }
+            });
+        }
+    }
+
+    STST_DEVICE static void entry(Args const &a) {
+        SweepGeometry const &g = a.geo;
+        const int lane = int(threadIdx.x) & (wave_size - 1);
+        const unsigned wave = __builtin_amdgcn_readfirstlane(
+            blockIdx.x * (blockDim.x / wave_size) + threadIdx.x / wave_size);
+        if (wave >= g.n_strips * g.n_chunks)
+            return;
+        const int strip = int(wave % g.n_strips);
+        const int chunk = int(wave / g.n_strips);
+        const int ya = g.out_begin + chunk * g.chunk_rows;
+        const int yb = ya + g.chunk_rows < g.out_end ? ya + g.chunk_rows : g.out_end;
+
+        if constexpr (INTERIOR_VARIANT) {
+            const int xw0 = strip * OW - GX;
+            const bool interior =
+                xw0 >= 0 && xw0 + LW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
+            if (interior)
+                run<false>(a, lane, strip, ya, yb);
+            else
+                run<true>(a, lane, strip, ya, yb);
+        } else {
+            run<true>(a, lane, strip, ya, yb);
+        }
+    }
+};
+
+template <typename SW>
+__global__ void __launch_bounds__(256) sweep_kernel(const typename SW::Args args) {
+    SW::entry(args);
+}
+
+// ------------------------------------------------------------------ host side
+inline int env_int(const char *name, int fallback) {
+    const char *v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : fallback;
+}
+
+// Rows of output per wave: enough waves to fill the chip several times over, but chunks long
+// enough that the 2*G warm-up rows stay a small fraction.
+inline int pick_chunk_rows(int out_rows, unsigned n_strips, int halo_rows) {
+    int forced = env_int("STSTHIP_CHUNK_ROWS", 0);
+    if (forced > 0)
+        return std::min(forced, std::max(out_rows, 1));
+    int cus = 256;
+    ststhip_compute_units(&cus);
+    const long target_waves = long(cus) * env_int("STSTHIP_WAVES_PER_CU", 16);
+    long chunks = std::max<long>(1, target_waves / std::max(1u, n_strips));
+    long rows = (out_rows + chunks - 1) / chunks;
+    rows = std::max<long>(rows, 8L * halo_rows);
+    rows = std::max<long>(rows, 16);
+    return int(std::min<long>(rows, std::max(out_rows, 1)));
+}
+
+// One kernel launch = T generations over global rows [out_begin, out_end).
+template <typename F, bool SOA, int T>
+void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDependentValue const *tdv,
+                  ststhip_domain const &dom, PlaneSet<typename F::Cell, SOA> const &src,
+                  PlaneSet<typename F::Cell, SOA> const &dst, std::uint64_t out_begin,
+                  std::uint64_t out_end, std::uint64_t iteration, ststhip_stream stream) {
+    using Tuning = SweepTuning<F, SOA>;
+    using SW = Sweep<F, SOA, T, Tuning::cells_per_lane, Tuning::prefetch_rows,
+                     Tuning::interior_variant>;
+    if (out_end <= out_begin || dom.global_width == 0)
+        return;
+    if (dom.global_height >= (1ull << 31) || dom.global_width >= (1ull << 31))
+        throw std::range_error("grid extents must be below 2^31 per dimension");
+
+    typename SW::Args args;
+    args.f = f;
+    args.halo = halo;
+    for (int t = 0; t < T; t++)
+        args.tdv[t] = tdv[t];
+    args.src = src;
+    args.dst = dst;
+    SweepGeometry &g = args.geo;
+    g.grid_h = std::int32_t(dom.global_height);
+    g.grid_w = std::int32_t(dom.global_width);
+    g.row_origin = std::int32_t(dom.row_origin);
+    g.load_lo = std::int32_t(std::max<std::int64_t>(0, dom.row_origin));
+    g.load_hi = std::int32_t(std::min<std::int64_t>(std::int64_t(dom.global_height),
+                                                    dom.row_origin + std::int64_t(dom.local_rows)));
+    g.out_begin = std::int32_t(out_begin);
+    g.out_end = std::int32_t(out_end);
+    g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW);
+    g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), g.n_strips, SW::G);
+    g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
+    g.pitch = dom.pitch;
+    g.iteration = iteration;
+
+    const unsigned waves = g.n_strips * g.n_chunks;
+    const unsigned waves_per_block = 4;
+    const unsigned blocks = (waves + waves_per_block - 1) / waves_per_block;
+    void *kernel_args[] = {&args};
+    check(ststhip_launch(reinterpret_cast<const void *>(&sweep_kernel<SW>), blocks, 1, 1,
+                         waves_per_block * wave_size, 1, 1, kernel_args, 0, stream),
+          "sweep launch");
+}
+
+// Runtime n_generations -> compiled T (powers of two up to the tuning's maximum).
+template <typename F, bool SOA, int T = SweepTuning<F, SOA>::max_generations>
+void dispatch_sweep(int n_generations, F const &f, typename F::Cell const &halo,
+                    typename F::TimeDependentValue const *tdv, ststhip_domain const &dom,
+                    PlaneSet<typename F::Cell, SOA> const &src,
+                    PlaneSet<typename F::Cell, SOA> const &dst, std::uint64_t out_begin,
+                    std::uint64_t out_end, std::uint64_t iteration, ststhip_stream stream) {
+    if (n_generations == T) {
+        launch_sweep<F, SOA, T>(f, halo, tdv, dom, src, dst, out_begin, out_end, iteration, stream);
+    } else if constexpr (T > 1) {
+        dispatch_sweep<F, SOA, T / 2>(n_generations, f, halo, tdv, dom, src, dst, out_begin,
+                                      out_end, iteration, stream);
+    } else {
+        throw std::invalid_argument("n_generations is not a compiled temporal-blocking depth");
+    }
+}
+
+// Largest compiled depth that fits into `remaining` generations.
+template <typename F, bool SOA> inline int next_pass_depth(std::uint64_t remaining) {
+    int t = SweepTuning<F, SOA>::max_generations;
+    int cap = env_int("STSTHIP_MAX_GENERATIONS", t);
+    while (t > 1 && (std::uint64_t(t) > remaining || t > cap))
+        t /= 2;
+    return t;
+}
+
+} // namespace internal
+} // namespace hip
+} // namespace stencil

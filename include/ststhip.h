@@ -1,0 +1,209 @@
+/*
+ * ststhip.h -- C ABI of the MI355X StencilUpdate backend (libststhip.so).
+ *
+ * Two layers, both `extern "C"`, plain pointers and sizes, int status codes
+ * (0 = success, otherwise a ststhip_status; ststhip_last_error() describes the
+ * last failure of the calling thread), no exceptions across the boundary.
+ *
+ * Layer 0 -- runtime services underneath the C++ templates.  In the reference
+ * these are the implicit services of the SYCL runtime behind
+ * cuda::StencilUpdate / cuda::Grid (queue creation and wait
+ * StencilStream/cuda/StencilUpdate.hpp:124-135, buffer allocation :204-205 and
+ * cuda/internal/Helpers.hpp:37-45, implicit host<->device copies behind
+ * host_accessor cuda/Grid.hpp:145-153, event profiling :184-198).
+ *
+ * Layer 1 -- the generation sweep itself for the precompiled transition
+ * functions (the five example applications and the reference's self-checking
+ * test function).  One call of ststhip_app_sweep() replaces the body of
+ * cuda::StencilUpdate::run_simulation's loop (StencilStream/cuda/
+ * StencilUpdate.hpp:212-273 AoS, :324-405 SoA) for `n_generations`
+ * generations at once (temporal blocking); ststhip_app_run() replaces
+ * cuda::StencilUpdate::operator() (:123-144).  This is the surface a foreign
+ * language binds (ctypes stub in INTEGRATION.md; stencilstream_amd/capi.py).
+ *
+ * Transition functions that only exist as C++ templates in the user's
+ * translation unit are compiled there (StencilStream/hip/StencilUpdate.hpp)
+ * and use layer 0 only.
+ */
+#ifndef STSTHIP_H
+#define STSTHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STSTHIP_ABI_VERSION 1
+
+typedef enum {
+    STSTHIP_OK = 0,
+    STSTHIP_ERR_HIP = 1,          /* a HIP runtime call failed               */
+    STSTHIP_ERR_INVALID = 2,      /* bad argument                            */
+    STSTHIP_ERR_UNKNOWN_APP = 3,  /* no such precompiled transition function */
+    STSTHIP_ERR_NO_DEVICE = 4,    /* no usable GPU                           */
+    STSTHIP_ERR_COMM = 5          /* RCCL failure                            */
+} ststhip_status;
+
+typedef void *ststhip_stream; /* a hipStream_t; NULL = the runtime's own stream */
+typedef void *ststhip_event;  /* a hipEvent_t */
+
+/* ------------------------------------------------------------- layer 0 */
+int ststhip_abi_version(void);
+const char *ststhip_last_error(void);
+
+/* Select a GPU for the calling process (device < 0: keep the current HIP device) and create the
+ * runtime's stream.  Idempotent.  Fails with STSTHIP_ERR_NO_DEVICE when no GPU is visible. */
+int ststhip_init(int device);
+int ststhip_shutdown(void);
+int ststhip_device_count(int *count);
+int ststhip_device_name(char *buf, size_t buf_size);
+int ststhip_compute_units(int *count);
+
+/* Device memory from a size-bucketed pool (freed blocks are reused, not returned to HIP). */
+int ststhip_malloc(void **ptr, size_t bytes);
+int ststhip_free(void *ptr);
+int ststhip_pool_trim(void);
+/* Pinned host memory for grids' host mirrors. */
+int ststhip_host_malloc(void **ptr, size_t bytes);
+int ststhip_host_free(void *ptr);
+
+/* Asynchronous on `stream`; the host buffer must stay alive until the stream is synchronised. */
+int ststhip_memcpy_h2d(void *dst, const void *src, size_t bytes, ststhip_stream stream);
+int ststhip_memcpy_d2h(void *dst, const void *src, size_t bytes, ststhip_stream stream);
+int ststhip_memcpy_d2d(void *dst, const void *src, size_t bytes, ststhip_stream stream);
+int ststhip_memset(void *dst, int value, size_t bytes, ststhip_stream stream);
+
+int ststhip_default_stream(ststhip_stream *stream);
+int ststhip_stream_create(ststhip_stream *stream);
+int ststhip_stream_destroy(ststhip_stream stream);
+int ststhip_stream_synchronize(ststhip_stream stream);
+int ststhip_stream_wait_event(ststhip_stream stream, ststhip_event event);
+
+int ststhip_event_create(ststhip_event *event);
+int ststhip_event_destroy(ststhip_event event);
+int ststhip_event_record(ststhip_event event, ststhip_stream stream);
+int ststhip_event_synchronize(ststhip_event event);
+int ststhip_event_elapsed_ms(ststhip_event start, ststhip_event stop, float *ms);
+
+/* Launch a kernel that lives in the caller's code object (`function` = host-side kernel symbol).
+ * Used by the C++ templates so that launches share the runtime's error handling and stream. */
+int ststhip_launch(const void *function, unsigned grid_x, unsigned grid_y, unsigned grid_z,
+                   unsigned block_x, unsigned block_y, unsigned block_z, void **args,
+                   size_t shared_bytes, ststhip_stream stream);
+
+/* AoS <-> per-field planes by byte geometry (the reference's scatter/gather kernels,
+ * StencilStream/cuda/StencilUpdate.hpp:294-321 and :408-438).  Field f of cell i is the
+ * `field_size[f]` bytes at aos + i*cell_size + field_offset[f]; plane f holds them densely.
+ * Staged through LDS so that both the AoS side and the plane side move whole cache lines. */
+int ststhip_scatter_fields(const void *aos, size_t cell_size, size_t n_cells, int n_fields,
+                           const size_t *field_offset, const size_t *field_size,
+                           void *const *planes, ststhip_stream stream);
+int ststhip_gather_fields(void *aos, size_t cell_size, size_t n_cells, int n_fields,
+                          const size_t *field_offset, const size_t *field_size,
+                          const void *const *planes, ststhip_stream stream);
+
+/* ------------------------------------------------------------- layer 1 */
+
+/* Where a buffer sits inside the global grid.  A single-GPU grid has row_origin = 0 and
+ * local_rows = global_height.  A row strip of a domain-decomposed grid holds its owned rows plus
+ * ghost rows: buffer row 0 is global row `row_origin` (may be "negative" for the first strip:
+ * rows before global row 0 are never read). */
+typedef struct {
+    uint64_t global_height; /* stencil.grid_range[0]                              */
+    uint64_t global_width;  /* stencil.grid_range[1]                              */
+    int64_t row_origin;     /* global row index of buffer row 0                   */
+    uint64_t local_rows;    /* rows held by the buffers                           */
+    uint64_t pitch;         /* elements between consecutive rows (>= global_width) */
+} ststhip_domain;
+
+/* Static description of a precompiled transition function. */
+typedef struct {
+    const char *name;
+    uint32_t cell_size;          /* sizeof(Cell) of the AoS cell                         */
+    uint32_t params_size;        /* sizeof of the transition function's parameter block  */
+    uint32_t stencil_radius;
+    uint32_t n_subiterations;
+    uint32_t n_planes;           /* 1 = AoS sweep; >1 = one plane per field (SoA sweep)  */
+    uint32_t plane_elem_size[16];
+    uint32_t field_offset[16];   /* byte offset of each plane's field inside the cell    */
+    uint32_t max_generations;    /* deepest temporal blocking compiled in                */
+    uint32_t tdv_size;           /* 0 = no time-dependent value                          */
+    uint32_t halo_depth_per_generation; /* ghost rows one generation consumes per side   */
+} ststhip_app_info;
+
+int ststhip_app_count(void);
+int ststhip_app_info_at(int index, ststhip_app_info *info);
+int ststhip_app_find(const char *name, ststhip_app_info *info);
+
+/* Advance global rows [out_row_begin, out_row_end) by `n_generations` (1 <= n <=
+ * max_generations) generations in ONE kernel launch, reading `src` and writing `dst` (arrays of
+ * n_planes device pointers with identical geometry `dom`).  Rows of `dst` outside the range are
+ * not touched.  Input rows [out_row_begin - g, out_row_end + g) that lie inside the global grid
+ * must be present in `src`, g = n_generations * halo_depth_per_generation.  `tf_params` is the
+ * host-side parameter block of the transition function, `halo_cell` one AoS cell.  The
+ * time-dependent values of generations `iteration .. iteration+n-1` are evaluated on the host
+ * inside this call, once each (reference: StencilStream/cuda/StencilUpdate.hpp:224). */
+int ststhip_app_sweep(const char *app, const void *tf_params, const void *halo_cell,
+                      const ststhip_domain *dom, const void *const *src, void *const *dst,
+                      uint64_t out_row_begin, uint64_t out_row_end, uint64_t iteration,
+                      uint32_t n_generations, ststhip_stream stream);
+
+/* Timing of one ststhip_app_run call. */
+typedef struct {
+    double walltime_s;        /* host wall clock around the whole call (incl. final sync)      */
+    double kernel_time_s;     /* sum of sweep-kernel durations from HIP events (if profiling)  */
+    uint64_t n_launches;      /* sweep kernels launched                                         */
+    uint64_t n_processed_cells; /* n_iterations * H * W (sub-iterations not counted)           */
+} ststhip_run_info;
+
+/* cuda::StencilUpdate::operator() for a precompiled transition function: advance the whole
+ * grid by n_iterations generations.  `src` is only read; `dst` receives the result; both are
+ * arrays of n_planes device pointers of geometry `dom` (row_origin 0, local_rows = height).
+ * Scratch planes come from the runtime's pool.  blocking != 0 synchronises the stream before
+ * returning; profiling != 0 brackets every sweep kernel with HIP events.  n_iterations == 0
+ * copies src to dst. */
+int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cell,
+                    const ststhip_domain *dom, const void *const *src, void *const *dst,
+                    uint64_t iteration_offset, uint64_t n_iterations, int blocking,
+                    int profiling, ststhip_stream stream, ststhip_run_info *info);
+
+/* Parameter blocks of the precompiled transition functions (plain data, host side). */
+typedef struct {
+    float coef[9]; /* as many as the variant takes; Jacobi9General: coef[r*3+c] */
+} ststhip_jacobi_params;
+typedef struct {
+    float Rx_1, Ry_1, Rz_1, Cap_1;
+} ststhip_hotspot_params;
+typedef struct {
+    float dt, t_0, tau, omega;
+    uint64_t cutoff_iteration, detect_iteration;
+    float source_radius_squared;
+    float source_r, source_c, source_distance_bound;
+    float double_center_rc;
+    uint32_t reserved;
+} ststhip_fdtd_params;
+
+/* ------------------------------------------------- multi-GPU ghost exchange */
+/* One process per GPU.  The unique id is created on rank 0 and distributed by the host program
+ * (torch.distributed / MPI / a file); every rank then joins.  Exchange = grouped ncclSend/ncclRecv
+ * with the upper (rank-1) and lower (rank+1) neighbour over the direct xGMI links. */
+#define STSTHIP_COMM_ID_BYTES 128
+typedef void *ststhip_comm;
+int ststhip_comm_unique_id(unsigned char id[STSTHIP_COMM_ID_BYTES]);
+int ststhip_comm_create(const unsigned char id[STSTHIP_COMM_ID_BYTES], int rank, int n_ranks,
+                        ststhip_comm *comm);
+int ststhip_comm_destroy(ststhip_comm comm);
+/* For every plane p: send `n_rows` rows starting at send_up[p] to rank-1 and at send_down[p] to
+ * rank+1, receive into recv_up[p] (from rank-1) and recv_down[p] (from rank+1).  row_bytes[p] =
+ * bytes of one row of plane p.  Ranks at the ends skip the missing neighbour. */
+int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *const *send_up,
+                               const void *const *send_down, void *const *recv_up,
+                               void *const *recv_down, const size_t *row_bytes, size_t n_rows,
+                               ststhip_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STSTHIP_H */

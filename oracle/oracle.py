@@ -66,6 +66,30 @@ def lib():
     return _LIB
 
 
+class use_fma_build:
+    """Context manager: route calls to the FMA-contracted build of the same source (x86 FMA
+    hardware needed).  Exists only to reproduce known answers recorded from such a build."""
+
+    def __enter__(self):
+        global _LIB
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_fma.so"])
+        self.saved = lib()
+        _LIB = C.CDLL(os.path.join(_HERE, "liboracle_fma.so"))
+        _LIB.oracle_fdtd_tdv.restype = C.c_float
+        return self
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self.saved
+
+
+def cpu_has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

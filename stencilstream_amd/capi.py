@@ -1,0 +1,258 @@
+"""ctypes binding of libststhip.so (include/ststhip.h).
+
+This is the binding a Python host uses for the precompiled transition functions; it contains no
+compute of its own and no CPU fallback: if the HIP library is missing or no GPU is visible, calls
+raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libststhip.so")
+
+STSTHIP_OK = 0
+STATUS_NAMES = {
+    0: "STSTHIP_OK",
+    1: "STSTHIP_ERR_HIP",
+    2: "STSTHIP_ERR_INVALID",
+    3: "STSTHIP_ERR_UNKNOWN_APP",
+    4: "STSTHIP_ERR_NO_DEVICE",
+    5: "STSTHIP_ERR_COMM",
+}
+COMM_ID_BYTES = 128
+
+
+class StsthipError(RuntimeError):
+    def __init__(self, status, what, message):
+        super().__init__(f"{what} failed with {STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class Domain(C.Structure):
+    """ststhip_domain"""
+
+    _fields_ = [
+        ("global_height", C.c_uint64),
+        ("global_width", C.c_uint64),
+        ("row_origin", C.c_int64),
+        ("local_rows", C.c_uint64),
+        ("pitch", C.c_uint64),
+    ]
+
+
+class AppInfo(C.Structure):
+    """ststhip_app_info"""
+
+    _fields_ = [
+        ("name", C.c_char_p),
+        ("cell_size", C.c_uint32),
+        ("params_size", C.c_uint32),
+        ("stencil_radius", C.c_uint32),
+        ("n_subiterations", C.c_uint32),
+        ("n_planes", C.c_uint32),
+        ("plane_elem_size", C.c_uint32 * 16),
+        ("field_offset", C.c_uint32 * 16),
+        ("max_generations", C.c_uint32),
+        ("tdv_size", C.c_uint32),
+        ("halo_depth_per_generation", C.c_uint32),
+    ]
+
+
+class RunInfo(C.Structure):
+    """ststhip_run_info"""
+
+    _fields_ = [
+        ("walltime_s", C.c_double),
+        ("kernel_time_s", C.c_double),
+        ("n_launches", C.c_uint64),
+        ("n_processed_cells", C.c_uint64),
+    ]
+
+
+class JacobiParams(C.Structure):
+    _fields_ = [("coef", C.c_float * 9)]
+
+
+class HotspotParams(C.Structure):
+    _fields_ = [("Rx_1", C.c_float), ("Ry_1", C.c_float), ("Rz_1", C.c_float), ("Cap_1", C.c_float)]
+
+
+class FdtdParams(C.Structure):
+    _fields_ = [
+        ("dt", C.c_float),
+        ("t_0", C.c_float),
+        ("tau", C.c_float),
+        ("omega", C.c_float),
+        ("cutoff_iteration", C.c_uint64),
+        ("detect_iteration", C.c_uint64),
+        ("source_radius_squared", C.c_float),
+        ("source_r", C.c_float),
+        ("source_c", C.c_float),
+        ("source_distance_bound", C.c_float),
+        ("double_center_rc", C.c_float),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class NoParams(C.Structure):
+    _fields_ = [("unused", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    """Load libststhip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C stencilstream_amd/csrc`; the MI355X backend has no CPU fallback"
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.ststhip_last_error.restype = C.c_char_p
+    vp, sz, u64, u32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32
+    pp = C.POINTER(C.c_void_p)
+    sigs = {
+        "ststhip_abi_version": [],
+        "ststhip_init": [C.c_int],
+        "ststhip_shutdown": [],
+        "ststhip_device_count": [C.POINTER(C.c_int)],
+        "ststhip_device_name": [C.c_char_p, sz],
+        "ststhip_compute_units": [C.POINTER(C.c_int)],
+        "ststhip_malloc": [pp, sz],
+        "ststhip_free": [vp],
+        "ststhip_pool_trim": [],
+        "ststhip_host_malloc": [pp, sz],
+        "ststhip_host_free": [vp],
+        "ststhip_memcpy_h2d": [vp, vp, sz, vp],
+        "ststhip_memcpy_d2h": [vp, vp, sz, vp],
+        "ststhip_memcpy_d2d": [vp, vp, sz, vp],
+        "ststhip_memset": [vp, C.c_int, sz, vp],
+        "ststhip_default_stream": [pp],
+        "ststhip_stream_create": [pp],
+        "ststhip_stream_destroy": [vp],
+        "ststhip_stream_synchronize": [vp],
+        "ststhip_stream_wait_event": [vp, vp],
+        "ststhip_event_create": [pp],
+        "ststhip_event_destroy": [vp],
+        "ststhip_event_record": [vp, vp],
+        "ststhip_event_synchronize": [vp],
+        "ststhip_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
+        "ststhip_launch": [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, pp, sz, vp],
+        "ststhip_scatter_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
+        "ststhip_gather_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
+        "ststhip_app_count": [],
+        "ststhip_app_info_at": [C.c_int, C.POINTER(AppInfo)],
+        "ststhip_app_find": [C.c_char_p, C.POINTER(AppInfo)],
+        "ststhip_app_sweep": [C.c_char_p, vp, vp, C.POINTER(Domain), pp, pp, u64, u64, u64, u32, vp],
+        "ststhip_app_run": [C.c_char_p, vp, vp, C.POINTER(Domain), pp, pp, u64, u64, C.c_int, C.c_int,
+                            vp, C.POINTER(RunInfo)],
+        "ststhip_comm_unique_id": [C.c_char_p],
+        "ststhip_comm_create": [C.c_char_p, C.c_int, C.c_int, pp],
+        "ststhip_comm_destroy": [vp],
+        "ststhip_comm_exchange_rows": [vp, C.c_int, pp, pp, pp, pp, C.POINTER(sz), sz, vp],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared entry point
+        fn.argtypes = argtypes
+        if name != "ststhip_last_error":
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+DECLARED_SYMBOLS = None
+
+
+def last_error():
+    msg = load().ststhip_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(status, what):
+    if status != STSTHIP_OK:
+        raise StsthipError(status, what, last_error())
+
+
+def init(device=-1):
+    check(load().ststhip_init(int(device)), "ststhip_init")
+
+
+def app_info(name):
+    info = AppInfo()
+    check(load().ststhip_app_find(name.encode(), C.byref(info)), f"ststhip_app_find({name})")
+    return info
+
+
+def list_apps():
+    lib = load()
+    out = []
+    for i in range(lib.ststhip_app_count()):
+        info = AppInfo()
+        check(lib.ststhip_app_info_at(i, C.byref(info)), "ststhip_app_info_at")
+        out.append(info.name.decode())
+    return out
+
+
+def _ptr_array(pointers):
+    arr = (C.c_void_p * len(pointers))(*[C.c_void_p(int(p)) for p in pointers])
+    return arr
+
+
+def app_sweep(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, out_begin, out_end, iteration,
+              n_generations, stream=0):
+    """One launch: n_generations generations over global rows [out_begin, out_end)."""
+    halo = C.create_string_buffer(bytes(halo_bytes), len(halo_bytes))
+    src = _ptr_array(src_ptrs)
+    dst = _ptr_array(dst_ptrs)
+    check(
+        load().ststhip_app_sweep(
+            app.encode(), C.cast(C.byref(tf_params), C.c_void_p), C.cast(halo, C.c_void_p),
+            C.byref(dom), src, dst, int(out_begin), int(out_end), int(iteration), int(n_generations),
+            C.c_void_p(int(stream)),
+        ),
+        f"ststhip_app_sweep({app})",
+    )
+
+
+def app_run(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, iteration_offset, n_iterations,
+            blocking=True, profiling=False, stream=0):
+    """cuda::StencilUpdate::operator() for a precompiled transition function."""
+    halo = C.create_string_buffer(bytes(halo_bytes), len(halo_bytes))
+    src = _ptr_array(src_ptrs)
+    dst = _ptr_array(dst_ptrs)
+    info = RunInfo()
+    check(
+        load().ststhip_app_run(
+            app.encode(), C.cast(C.byref(tf_params), C.c_void_p), C.cast(halo, C.c_void_p),
+            C.byref(dom), src, dst, int(iteration_offset), int(n_iterations), int(bool(blocking)),
+            int(bool(profiling)), C.c_void_p(int(stream)), C.byref(info),
+        ),
+        f"ststhip_app_run({app})",
+    )
+    return info
+
+
+def scatter_fields(aos_ptr, cell_size, n_cells, offsets, sizes, plane_ptrs, stream=0):
+    n = len(offsets)
+    off = (C.c_size_t * n)(*offsets)
+    siz = (C.c_size_t * n)(*sizes)
+    check(
+        load().ststhip_scatter_fields(C.c_void_p(int(aos_ptr)), cell_size, n_cells, n, off, siz,
+                                      _ptr_array(plane_ptrs), C.c_void_p(int(stream))),
+        "ststhip_scatter_fields",
+    )
+
+
+def gather_fields(aos_ptr, cell_size, n_cells, offsets, sizes, plane_ptrs, stream=0):
+    n = len(offsets)
+    off = (C.c_size_t * n)(*offsets)
+    siz = (C.c_size_t * n)(*sizes)
+    check(
+        load().ststhip_gather_fields(C.c_void_p(int(aos_ptr)), cell_size, n_cells, n, off, siz,
+                                     _ptr_array(plane_ptrs), C.c_void_p(int(stream))),
+        "ststhip_gather_fields",
+    )

@@ -1,0 +1,94 @@
+// Glue between the precompiled transition functions (apps/*.hpp) and layer 1 of the C ABI
+// (include/ststhip.h: ststhip_app_*).  Each application translation unit instantiates the same
+// sweep templates a C++ user would (StencilStream/hip/internal/Sweep.hpp) and registers a
+// type-erased entry here.
+#pragma once
+#include <StencilStream/hip/internal/Sweep.hpp>
+#include <ststhip.h>
+
+#include <cstring>
+#include <exception>
+#include <vector>
+
+namespace ststhip_detail {
+
+struct AppEntry {
+    ststhip_app_info info;
+    int (*sweep)(const void *tf_params, const void *halo_cell, const ststhip_domain *dom,
+                 const void *const *src, void *const *dst, std::uint64_t out_begin,
+                 std::uint64_t out_end, std::uint64_t iteration, std::uint32_t n_generations,
+                 ststhip_stream stream);
+};
+
+void register_app(AppEntry const &entry);
+const AppEntry *find_app(const char *name);
+void set_error(const char *message);
+int fail(int status, const char *message);
+
+template <typename F, bool SOA> struct AppAdapter {
+    using Cell = typename F::Cell;
+    using TDV = typename F::TimeDependentValue;
+    using Planes = stencil::hip::internal::PlaneSet<Cell, SOA>;
+    using Tuning = stencil::hip::SweepTuning<F, SOA>;
+
+    static int sweep(const void *tf_params, const void *halo_cell, const ststhip_domain *dom,
+                     const void *const *src, void *const *dst, std::uint64_t out_begin,
+                     std::uint64_t out_end, std::uint64_t iteration, std::uint32_t n_generations,
+                     ststhip_stream stream) {
+        try {
+            typename F::Block block;
+            std::memcpy(&block, tf_params, sizeof block);
+            const F f = F::from_params(block);
+            Cell halo;
+            std::memcpy(static_cast<void *>(&halo), halo_cell, sizeof(Cell));
+            TDV tdv[Tuning::max_generations];
+            for (std::uint32_t t = 0; t < n_generations && t < std::uint32_t(Tuning::max_generations); t++)
+                tdv[t] = f.get_time_dependent_value(iteration + t);
+            Planes s, d;
+            for (int i = 0; i < Planes::n_planes; i++) {
+                s.plane[i] = const_cast<void *>(src[i]);
+                d.plane[i] = dst[i];
+            }
+            stencil::hip::internal::dispatch_sweep<F, SOA>(int(n_generations), f, halo, tdv, *dom,
+                                                           s, d, out_begin, out_end, iteration,
+                                                           stream);
+            return STSTHIP_OK;
+        } catch (stencil::hip::internal::runtime_error const &e) {
+            return e.status; // message already recorded by the failing runtime call
+        } catch (std::exception const &e) {
+            return fail(STSTHIP_ERR_INVALID, e.what());
+        }
+    }
+
+    static AppEntry make(const char *name) {
+        AppEntry e;
+        std::memset(&e.info, 0, sizeof e.info);
+        e.info.name = name;
+        e.info.cell_size = sizeof(Cell);
+        e.info.params_size = sizeof(typename F::Block);
+        e.info.stencil_radius = std::uint32_t(F::stencil_radius);
+        e.info.n_subiterations = std::uint32_t(F::n_subiterations);
+        e.info.n_planes = Planes::n_planes;
+        for (int i = 0; i < Planes::n_planes; i++) {
+            e.info.plane_elem_size[i] = std::uint32_t(Planes::elem_size(i));
+            e.info.field_offset[i] = std::uint32_t(Planes::elem_offset(i));
+        }
+        e.info.max_generations = Tuning::max_generations;
+        e.info.tdv_size = std::is_same_v<TDV, std::monostate> ? 0 : std::uint32_t(sizeof(TDV));
+        e.info.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
+        e.sweep = &sweep;
+        return e;
+    }
+};
+
+struct AppRegistrar {
+    AppRegistrar(AppEntry const &entry) { register_app(entry); }
+};
+
+} // namespace ststhip_detail
+
+#define STSTHIP_CONCAT2(a, b) a##b
+#define STSTHIP_CONCAT(a, b) STSTHIP_CONCAT2(a, b)
+#define STSTHIP_REGISTER_APP(name, F, SOA)                                                         \
+    static ::ststhip_detail::AppRegistrar STSTHIP_CONCAT(ststhip_app_registrar_, __COUNTER__)(     \
+        ::ststhip_detail::AppAdapter<F, SOA>::make(name))

@@ -1,0 +1,746 @@
+// libststhip.so -- C-ABI runtime of the MI355X StencilUpdate backend (include/ststhip.h).
+//
+// Layer 0: device selection, one runtime stream, a size-bucketed HBM pool, pinned host memory,
+// async copies, events, kernel launch, LDS-staged AoS<->planes transforms, RCCL ghost-row exchange.
+// Layer 1: registry and drivers for the precompiled transition functions (app_*.hip).
+#include "app_registry.hpp"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace ststhip_detail {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *message) { g_last_error = message ? message : ""; }
+int fail(int status, const char *message) {
+    set_error(message);
+    return status;
+}
+
+static int hip_fail(hipError_t err, const char *what) {
+    std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+    g_last_error = msg;
+    return STSTHIP_ERR_HIP;
+}
+
+#define HIP_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t err_ = (call);                                                                  \
+        if (err_ != hipSuccess)                                                                    \
+            return hip_fail(err_, #call);                                                          \
+    } while (0)
+
+struct Runtime {
+    std::mutex lock;
+    bool up = false;
+    int device = -1;
+    int compute_units = 256;
+    hipStream_t stream = nullptr;
+    // pool: bucket size -> free blocks; live: ptr -> bucket size
+    std::multimap<std::size_t, void *> free_blocks;
+    std::map<void *, std::size_t> live_blocks;
+};
+static Runtime &rt() {
+    static Runtime r;
+    return r;
+}
+
+static std::vector<AppEntry> &apps() {
+    static std::vector<AppEntry> registry;
+    return registry;
+}
+void register_app(AppEntry const &entry) { apps().push_back(entry); }
+const AppEntry *find_app(const char *name) {
+    if (!name)
+        return nullptr;
+    for (auto const &e : apps())
+        if (std::strcmp(e.info.name, name) == 0)
+            return &e;
+    return nullptr;
+}
+
+static hipStream_t resolve(ststhip_stream s) { return s ? static_cast<hipStream_t>(s) : rt().stream; }
+
+static std::size_t bucket_of(std::size_t bytes) {
+    // powers of two up to 1 MiB, then multiples of 2 MiB (HBM is plentiful: 288 GB)
+    if (bytes <= (1u << 20)) {
+        std::size_t b = 256;
+        while (b < bytes)
+            b <<= 1;
+        return b;
+    }
+    const std::size_t step = std::size_t(2) << 20;
+    return (bytes + step - 1) / step * step;
+}
+
+// ------------------------------------------------------------------ AoS <-> planes kernels
+struct FieldTable {
+    int n_fields;
+    unsigned offset[16];
+    unsigned size[16];
+    void *plane[16];
+};
+
+constexpr int transform_tile = 256; // cells per workgroup
+
+template <typename W>
+__device__ inline void copy_field(unsigned char *dst, const unsigned char *src) {
+    *reinterpret_cast<W *>(dst) = *reinterpret_cast<const W *>(src);
+}
+
+__device__ inline void copy_bytes(unsigned char *dst, const unsigned char *src, unsigned size) {
+    if ((size & 3u) == 0 && ((reinterpret_cast<std::uintptr_t>(dst) |
+                              reinterpret_cast<std::uintptr_t>(src)) & 3u) == 0) {
+        for (unsigned b = 0; b < size; b += 4)
+            copy_field<std::uint32_t>(dst + b, src + b);
+    } else {
+        for (unsigned b = 0; b < size; b++)
+            dst[b] = src[b];
+    }
+}
+
+// AoS tile -> LDS with whole-line loads, then each lane peels one cell's fields into the planes.
+__global__ void __launch_bounds__(transform_tile)
+    scatter_kernel(const unsigned char *aos, unsigned cell_size, std::size_t n_cells, FieldTable table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+    const std::size_t first = std::size_t(blockIdx.x) * transform_tile;
+    const std::size_t cells_here = n_cells - first < transform_tile ? n_cells - first : transform_tile;
+    const std::size_t tile_bytes = cells_here * cell_size;
+    const unsigned char *src = aos + first * cell_size;
+    if ((cell_size & 3u) == 0) {
+        for (std::size_t w = threadIdx.x; w < tile_bytes / 4; w += transform_tile)
+            reinterpret_cast<std::uint32_t *>(tile)[w] = reinterpret_cast<const std::uint32_t *>(src)[w];
+    } else {
+        for (std::size_t b = threadIdx.x; b < tile_bytes; b += transform_tile)
+            tile[b] = src[b];
+    }
+    __syncthreads();
+    if (threadIdx.x < cells_here) {
+        const unsigned char *cell = tile + std::size_t(threadIdx.x) * cell_size;
+        for (int f = 0; f < table.n_fields; f++) {
+            unsigned char *out = static_cast<unsigned char *>(table.plane[f]) +
+                                 (first + threadIdx.x) * table.size[f];
+            copy_bytes(out, cell + table.offset[f], table.size[f]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(transform_tile)
+    gather_kernel(unsigned char *aos, unsigned cell_size, std::size_t n_cells, FieldTable table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+    const std::size_t first = std::size_t(blockIdx.x) * transform_tile;
+    const std::size_t cells_here = n_cells - first < transform_tile ? n_cells - first : transform_tile;
+    const std::size_t tile_bytes = cells_here * cell_size;
+    // bytes of the cell that no field covers stay zero (the reference gathers into a
+    // default-constructed cell, cuda/StencilUpdate.hpp:424)
+    for (std::size_t b = threadIdx.x; b < tile_bytes; b += transform_tile)
+        tile[b] = 0;
+    __syncthreads();
+    if (threadIdx.x < cells_here) {
+        unsigned char *cell = tile + std::size_t(threadIdx.x) * cell_size;
+        for (int f = 0; f < table.n_fields; f++) {
+            const unsigned char *in = static_cast<const unsigned char *>(table.plane[f]) +
+                                      (first + threadIdx.x) * table.size[f];
+            copy_bytes(cell + table.offset[f], in, table.size[f]);
+        }
+    }
+    __syncthreads();
+    unsigned char *dst = aos + first * cell_size;
+    if ((cell_size & 3u) == 0) {
+        for (std::size_t w = threadIdx.x; w < tile_bytes / 4; w += transform_tile)
+            reinterpret_cast<std::uint32_t *>(dst)[w] = reinterpret_cast<const std::uint32_t *>(tile)[w];
+    } else {
+        for (std::size_t b = threadIdx.x; b < tile_bytes; b += transform_tile)
+            dst[b] = tile[b];
+    }
+}
+
+static int fill_table(FieldTable &t, std::size_t cell_size, int n_fields, const size_t *offset,
+                      const size_t *size, void *const *planes) {
+    if (n_fields < 1 || n_fields > 16 || cell_size == 0 || cell_size > 256)
+        return fail(STSTHIP_ERR_INVALID, "scatter/gather: need 1..16 fields and cells of 1..256 bytes");
+    t.n_fields = n_fields;
+    for (int f = 0; f < n_fields; f++) {
+        if (offset[f] + size[f] > cell_size || size[f] == 0)
+            return fail(STSTHIP_ERR_INVALID, "scatter/gather: field outside the cell");
+        t.offset[f] = unsigned(offset[f]);
+        t.size[f] = unsigned(size[f]);
+        t.plane[f] = planes[f];
+    }
+    return STSTHIP_OK;
+}
+
+// ------------------------------------------------------------------ RCCL, loaded on first use
+struct Id128 {
+    char bytes[128];
+};
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128 /* ncclUniqueId, passed by value */, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static Rccl &rccl() {
+    static Rccl r;
+    return r;
+}
+static int load_rccl() {
+    Rccl &r = rccl();
+    if (r.handle)
+        return STSTHIP_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle)
+            break;
+    }
+    if (!r.handle)
+        return fail(STSTHIP_ERR_COMM, "cannot load librccl.so");
+    bool ok = true;
+    auto sym = [&](const char *name) {
+        void *p = dlsym(r.handle, name);
+        ok = ok && p;
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok)
+        return fail(STSTHIP_ERR_COMM, "librccl.so lacks a required symbol");
+    return STSTHIP_OK;
+}
+static int nccl_fail(int code, const char *what) {
+    std::string msg = std::string(what) + ": " +
+                      (rccl().GetErrorString ? rccl().GetErrorString(code) : "rccl error");
+    g_last_error = msg;
+    return STSTHIP_ERR_COMM;
+}
+#define NCCL_TRY(call)                                                                             \
+    do {                                                                                           \
+        int rc_ = (call);                                                                          \
+        if (rc_ != 0)                                                                              \
+            return nccl_fail(rc_, #call);                                                          \
+    } while (0)
+
+struct Comm {
+    void *nccl = nullptr;
+    int rank = 0, n_ranks = 1;
+};
+
+} // namespace ststhip_detail
+
+using namespace ststhip_detail;
+
+extern "C" {
+
+int ststhip_abi_version(void) { return STSTHIP_ABI_VERSION; }
+const char *ststhip_last_error(void) { return g_last_error.c_str(); }
+
+int ststhip_init(int device) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> guard(r.lock);
+    if (r.up && (device < 0 || device == r.device))
+        return STSTHIP_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(STSTHIP_ERR_NO_DEVICE, "no HIP device visible: the MI355X backend has no CPU fallback");
+    if (device >= count)
+        return fail(STSTHIP_ERR_INVALID, "device index out of range");
+    if (r.up && device != r.device)
+        return fail(STSTHIP_ERR_INVALID, "runtime already bound to another device of this process");
+    if (device >= 0)
+        HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipGetDevice(&r.device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, r.device));
+    r.compute_units = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    r.up = true;
+    return STSTHIP_OK;
+}
+
+int ststhip_shutdown(void) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> guard(r.lock);
+    if (!r.up)
+        return STSTHIP_OK;
+    hipStreamSynchronize(r.stream);
+    for (auto &kv : r.free_blocks)
+        hipFree(kv.second);
+    r.free_blocks.clear();
+    hipStreamDestroy(r.stream);
+    r.stream = nullptr;
+    r.up = false;
+    return STSTHIP_OK;
+}
+
+int ststhip_device_count(int *count) {
+    if (!count)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (hipGetDeviceCount(count) != hipSuccess)
+        *count = 0;
+    return STSTHIP_OK;
+}
+
+int ststhip_device_name(char *buf, size_t buf_size) {
+    if (!buf || buf_size == 0)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    std::snprintf(buf, buf_size, "%s (%s)", prop.name, prop.gcnArchName);
+    return STSTHIP_OK;
+}
+
+int ststhip_compute_units(int *count) {
+    if (!count)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    *count = rt().compute_units;
+    return STSTHIP_OK;
+}
+
+int ststhip_malloc(void **ptr, size_t bytes) {
+    if (!ptr)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    Runtime &r = rt();
+    const std::size_t bucket = bucket_of(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> guard(r.lock);
+        auto it = r.free_blocks.find(bucket);
+        if (it != r.free_blocks.end()) {
+            *ptr = it->second;
+            r.free_blocks.erase(it);
+            r.live_blocks[*ptr] = bucket;
+            return STSTHIP_OK;
+        }
+    }
+    void *p = nullptr;
+    hipError_t err = hipMalloc(&p, bucket);
+    if (err != hipSuccess) {
+        ststhip_pool_trim();
+        err = hipMalloc(&p, bucket);
+    }
+    if (err != hipSuccess)
+        return hip_fail(err, "hipMalloc");
+    std::lock_guard<std::mutex> guard(r.lock);
+    r.live_blocks[p] = bucket;
+    *ptr = p;
+    return STSTHIP_OK;
+}
+
+int ststhip_free(void *ptr) {
+    if (!ptr)
+        return STSTHIP_OK;
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> guard(r.lock);
+    auto it = r.live_blocks.find(ptr);
+    if (it == r.live_blocks.end())
+        return fail(STSTHIP_ERR_INVALID, "ststhip_free: pointer not from ststhip_malloc");
+    if (r.up)
+        r.free_blocks.emplace(it->second, ptr); // reused in stream order by later allocations
+    r.live_blocks.erase(it);
+    return STSTHIP_OK;
+}
+
+int ststhip_pool_trim(void) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> guard(r.lock);
+    if (r.up)
+        hipStreamSynchronize(r.stream);
+    for (auto &kv : r.free_blocks)
+        hipFree(kv.second);
+    r.free_blocks.clear();
+    return STSTHIP_OK;
+}
+
+int ststhip_host_malloc(void **ptr, size_t bytes) {
+    if (!ptr)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return STSTHIP_OK;
+}
+
+int ststhip_host_free(void *ptr) {
+    if (ptr && rt().up)
+        HIP_TRY(hipHostFree(ptr));
+    return STSTHIP_OK;
+}
+
+int ststhip_memcpy_h2d(void *dst, const void *src, size_t bytes, ststhip_stream stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, resolve(stream)));
+    return STSTHIP_OK;
+}
+int ststhip_memcpy_d2h(void *dst, const void *src, size_t bytes, ststhip_stream stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, resolve(stream)));
+    return STSTHIP_OK;
+}
+int ststhip_memcpy_d2d(void *dst, const void *src, size_t bytes, ststhip_stream stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, resolve(stream)));
+    return STSTHIP_OK;
+}
+int ststhip_memset(void *dst, int value, size_t bytes, ststhip_stream stream) {
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, resolve(stream)));
+    return STSTHIP_OK;
+}
+
+int ststhip_default_stream(ststhip_stream *stream) {
+    if (!stream)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    *stream = rt().stream;
+    return STSTHIP_OK;
+}
+int ststhip_stream_create(ststhip_stream *stream) {
+    if (!stream)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return STSTHIP_OK;
+}
+int ststhip_stream_destroy(ststhip_stream stream) {
+    if (stream)
+        HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return STSTHIP_OK;
+}
+int ststhip_stream_synchronize(ststhip_stream stream) {
+    if (!rt().up && !stream)
+        return STSTHIP_OK;
+    HIP_TRY(hipStreamSynchronize(resolve(stream)));
+    return STSTHIP_OK;
+}
+int ststhip_stream_wait_event(ststhip_stream stream, ststhip_event event) {
+    HIP_TRY(hipStreamWaitEvent(resolve(stream), static_cast<hipEvent_t>(event), 0));
+    return STSTHIP_OK;
+}
+
+int ststhip_event_create(ststhip_event *event) {
+    if (!event)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *event = e;
+    return STSTHIP_OK;
+}
+int ststhip_event_destroy(ststhip_event event) {
+    if (event)
+        HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return STSTHIP_OK;
+}
+int ststhip_event_record(ststhip_event event, ststhip_stream stream) {
+    HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), resolve(stream)));
+    return STSTHIP_OK;
+}
+int ststhip_event_synchronize(ststhip_event event) {
+    HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return STSTHIP_OK;
+}
+int ststhip_event_elapsed_ms(ststhip_event start, ststhip_event stop, float *ms) {
+    if (!ms)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return STSTHIP_OK;
+}
+
+int ststhip_launch(const void *function, unsigned grid_x, unsigned grid_y, unsigned grid_z,
+                   unsigned block_x, unsigned block_y, unsigned block_z, void **args,
+                   size_t shared_bytes, ststhip_stream stream) {
+    if (!function || grid_x == 0 || grid_y == 0 || grid_z == 0)
+        return fail(STSTHIP_ERR_INVALID, "ststhip_launch: empty grid or null kernel");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    HIP_TRY(hipLaunchKernel(function, dim3(grid_x, grid_y, grid_z), dim3(block_x, block_y, block_z),
+                            args, shared_bytes, resolve(stream)));
+    return STSTHIP_OK;
+}
+
+int ststhip_scatter_fields(const void *aos, size_t cell_size, size_t n_cells, int n_fields,
+                           const size_t *field_offset, const size_t *field_size,
+                           void *const *planes, ststhip_stream stream) {
+    if (!aos || !field_offset || !field_size || !planes)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    FieldTable table;
+    if (int rc = fill_table(table, cell_size, n_fields, field_offset, field_size, planes))
+        return rc;
+    if (n_cells == 0)
+        return STSTHIP_OK;
+    const unsigned blocks = unsigned((n_cells + transform_tile - 1) / transform_tile);
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(transform_tile),
+                       transform_tile * cell_size, resolve(stream),
+                       static_cast<const unsigned char *>(aos), unsigned(cell_size), n_cells, table);
+    HIP_TRY(hipGetLastError());
+    return STSTHIP_OK;
+}
+
+int ststhip_gather_fields(void *aos, size_t cell_size, size_t n_cells, int n_fields,
+                          const size_t *field_offset, const size_t *field_size,
+                          const void *const *planes, ststhip_stream stream) {
+    if (!aos || !field_offset || !field_size || !planes)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    FieldTable table;
+    if (int rc = fill_table(table, cell_size, n_fields, field_offset, field_size,
+                            const_cast<void *const *>(planes)))
+        return rc;
+    if (n_cells == 0)
+        return STSTHIP_OK;
+    const unsigned blocks = unsigned((n_cells + transform_tile - 1) / transform_tile);
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(transform_tile), transform_tile * cell_size,
+                       resolve(stream), static_cast<unsigned char *>(aos), unsigned(cell_size),
+                       n_cells, table);
+    HIP_TRY(hipGetLastError());
+    return STSTHIP_OK;
+}
+
+// ------------------------------------------------------------------ layer 1
+int ststhip_app_count(void) { return int(apps().size()); }
+
+int ststhip_app_info_at(int index, ststhip_app_info *info) {
+    if (!info || index < 0 || index >= int(apps().size()))
+        return fail(STSTHIP_ERR_INVALID, "app index out of range");
+    *info = apps()[index].info;
+    return STSTHIP_OK;
+}
+
+int ststhip_app_find(const char *name, ststhip_app_info *info) {
+    const AppEntry *e = find_app(name);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    if (info)
+        *info = e->info;
+    return STSTHIP_OK;
+}
+
+static int check_domain(const AppEntry *e, const ststhip_domain *dom, std::uint64_t out_begin,
+                        std::uint64_t out_end, std::uint32_t n_generations) {
+    if (!dom)
+        return fail(STSTHIP_ERR_INVALID, "null domain");
+    if (dom->pitch < dom->global_width)
+        return fail(STSTHIP_ERR_INVALID, "pitch smaller than the grid width");
+    if (out_end > dom->global_height || out_begin > out_end)
+        return fail(STSTHIP_ERR_INVALID, "output rows outside the grid");
+    if (n_generations < 1 || n_generations > e->info.max_generations ||
+        (n_generations & (n_generations - 1)) != 0)
+        return fail(STSTHIP_ERR_INVALID,
+                    "n_generations must be a power of two up to the app's max_generations");
+    // every input row the sweep reads must be inside the buffers: this is what keeps a
+    // hand-written kernel from touching memory it does not own
+    const std::int64_t g = std::int64_t(n_generations) * e->info.halo_depth_per_generation;
+    const std::int64_t need_lo = std::max<std::int64_t>(0, std::int64_t(out_begin) - g);
+    const std::int64_t need_hi =
+        std::min<std::int64_t>(std::int64_t(dom->global_height), std::int64_t(out_end) + g);
+    if (out_end > out_begin &&
+        (need_lo < dom->row_origin || need_hi > dom->row_origin + std::int64_t(dom->local_rows)))
+        return fail(STSTHIP_ERR_INVALID, "buffers do not hold the ghost rows this sweep reads");
+    return STSTHIP_OK;
+}
+
+int ststhip_app_sweep(const char *app, const void *tf_params, const void *halo_cell,
+                      const ststhip_domain *dom, const void *const *src, void *const *dst,
+                      uint64_t out_row_begin, uint64_t out_row_end, uint64_t iteration,
+                      uint32_t n_generations, ststhip_stream stream) {
+    const AppEntry *e = find_app(app);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    if (!tf_params || !halo_cell || !src || !dst)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    for (unsigned p = 0; p < e->info.n_planes; p++)
+        if (!src[p] || !dst[p] || src[p] == dst[p])
+            return fail(STSTHIP_ERR_INVALID, "source and target planes must be distinct non-null buffers");
+    if (int rc = check_domain(e, dom, out_row_begin, out_row_end, n_generations))
+        return rc;
+    if (int rc = ststhip_init(-1))
+        return rc;
+    return e->sweep(tf_params, halo_cell, dom, src, dst, out_row_begin, out_row_end, iteration,
+                    n_generations, resolve(stream));
+}
+
+int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cell,
+                    const ststhip_domain *dom, const void *const *src, void *const *dst,
+                    uint64_t iteration_offset, uint64_t n_iterations, int blocking, int profiling,
+                    ststhip_stream stream, ststhip_run_info *info) {
+    const AppEntry *e = find_app(app);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    if (!tf_params || !halo_cell || !src || !dst || !dom)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (dom->row_origin != 0 || dom->local_rows != dom->global_height)
+        return fail(STSTHIP_ERR_INVALID, "ststhip_app_run works on whole grids (row_origin 0)");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    hipStream_t s = resolve(stream);
+    const unsigned n_planes = e->info.n_planes;
+    const std::size_t plane_cells = std::size_t(dom->local_rows) * dom->pitch;
+    auto started = std::chrono::high_resolution_clock::now();
+
+    // passes: greedy powers of two
+    std::vector<std::uint32_t> depths;
+    {
+        int cap = stencil::hip::internal::env_int("STSTHIP_MAX_GENERATIONS", int(e->info.max_generations));
+        std::uint64_t remaining = n_iterations;
+        while (remaining > 0) {
+            std::uint32_t t = e->info.max_generations;
+            while (t > 1 && (t > remaining || int(t) > cap))
+                t /= 2;
+            depths.push_back(t);
+            remaining -= t;
+        }
+    }
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    int rc = STSTHIP_OK;
+    void *scratch[16] = {nullptr};
+    if (depths.empty()) {
+        for (unsigned p = 0; p < n_planes && rc == STSTHIP_OK; p++)
+            rc = ststhip_memcpy_d2d(dst[p], src[p], plane_cells * e->info.plane_elem_size[p], s);
+    } else {
+        if (depths.size() > 1)
+            for (unsigned p = 0; p < n_planes && rc == STSTHIP_OK; p++)
+                rc = ststhip_malloc(&scratch[p], plane_cells * e->info.plane_elem_size[p]);
+        // the last pass must land in dst; the input is never written
+        const void *const *from = src;
+        std::uint64_t iteration = iteration_offset;
+        for (std::size_t pass = 0; pass < depths.size() && rc == STSTHIP_OK; pass++) {
+            const bool into_dst = ((depths.size() - 1 - pass) % 2) == 0;
+            void *const *to = into_dst ? dst : scratch;
+            hipEvent_t a = nullptr, b = nullptr;
+            if (profiling) {
+                hipEventCreate(&a);
+                hipEventCreate(&b);
+                hipEventRecord(a, s);
+            }
+            rc = ststhip_app_sweep(app, tf_params, halo_cell, dom, from, to, 0, dom->global_height,
+                                   iteration, depths[pass], s);
+            if (profiling) {
+                hipEventRecord(b, s);
+                events.emplace_back(a, b);
+            }
+            from = const_cast<const void *const *>(to);
+            iteration += depths[pass];
+        }
+    }
+    if (rc == STSTHIP_OK && (blocking || profiling)) {
+        hipError_t err = hipStreamSynchronize(s);
+        if (err != hipSuccess)
+            rc = hip_fail(err, "hipStreamSynchronize");
+    }
+    for (unsigned p = 0; p < n_planes; p++)
+        if (scratch[p])
+            ststhip_free(scratch[p]);
+    double kernel_s = 0.0;
+    for (auto &ev : events) {
+        float ms = 0.0f;
+        if (rc == STSTHIP_OK && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess)
+            kernel_s += double(ms) * 1e-3;
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    if (info) {
+        std::chrono::duration<double> elapsed = std::chrono::high_resolution_clock::now() - started;
+        info->walltime_s = elapsed.count();
+        info->kernel_time_s = kernel_s;
+        info->n_launches = depths.size();
+        info->n_processed_cells = n_iterations * dom->global_height * dom->global_width;
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------ multi-GPU
+int ststhip_comm_unique_id(unsigned char id[STSTHIP_COMM_ID_BYTES]) {
+    if (!id)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = load_rccl())
+        return rc;
+    NCCL_TRY(rccl().GetUniqueId(id));
+    return STSTHIP_OK;
+}
+
+int ststhip_comm_create(const unsigned char id[STSTHIP_COMM_ID_BYTES], int rank, int n_ranks,
+                        ststhip_comm *comm) {
+    if (!id || !comm || rank < 0 || rank >= n_ranks)
+        return fail(STSTHIP_ERR_INVALID, "bad communicator arguments");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    if (int rc = load_rccl())
+        return rc;
+    Id128 uid;
+    std::memcpy(uid.bytes, id, sizeof uid.bytes);
+    Comm *c = new Comm;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    int rc = rccl().CommInitRank(&c->nccl, n_ranks, uid, rank);
+    if (rc != 0) {
+        delete c;
+        return nccl_fail(rc, "ncclCommInitRank");
+    }
+    *comm = c;
+    return STSTHIP_OK;
+}
+
+int ststhip_comm_destroy(ststhip_comm comm) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c)
+        return STSTHIP_OK;
+    if (c->nccl)
+        rccl().CommDestroy(c->nccl);
+    delete c;
+    return STSTHIP_OK;
+}
+
+int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *const *send_up,
+                               const void *const *send_down, void *const *recv_up,
+                               void *const *recv_down, const size_t *row_bytes, size_t n_rows,
+                               ststhip_stream stream) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c || n_planes < 1 || n_planes > 16 || !row_bytes)
+        return fail(STSTHIP_ERR_INVALID, "bad exchange arguments");
+    if (n_rows == 0)
+        return STSTHIP_OK;
+    hipStream_t s = resolve(stream);
+    const int ncclChar = 0;
+    const bool has_up = c->rank > 0, has_down = c->rank + 1 < c->n_ranks;
+    NCCL_TRY(rccl().GroupStart());
+    for (int p = 0; p < n_planes; p++) {
+        const size_t bytes = row_bytes[p] * n_rows;
+        if (has_up) {
+            NCCL_TRY(rccl().Send(send_up[p], bytes, ncclChar, c->rank - 1, c->nccl, s));
+            NCCL_TRY(rccl().Recv(recv_up[p], bytes, ncclChar, c->rank - 1, c->nccl, s));
+        }
+        if (has_down) {
+            NCCL_TRY(rccl().Send(send_down[p], bytes, ncclChar, c->rank + 1, c->nccl, s));
+            NCCL_TRY(rccl().Recv(recv_down[p], bytes, ncclChar, c->rank + 1, c->nccl, s));
+        }
+    }
+    NCCL_TRY(rccl().GroupEnd());
+    return STSTHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,132 @@
+"""The oracle against every known answer we have for this path (CPU only).
+
+Pins: (1) the reference's own self-checking known-answer test of the update machinery
+(tests/cpu/StencilUpdate.cpp:35-41 with tests/TransFuncs.hpp:55-104), restated; (2) the known
+answers of the reference's cpu backend recorded in SURVEY.md section 8c; (3) Rodinia's OpenMP
+HotSpot built from the reference tree when it is present."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+KNOWN = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+
+
+def load_conway():
+    chars = [ch for ch in open(os.path.join(GOLDEN, KNOWN["conway"]["input"])).read() if ch in "X."]
+    return (np.array(chars) == "X").astype(np.uint8).reshape(64, 64)
+
+
+def conway_stdout(grid):
+    return "".join("".join("X" if v else "." for v in row) + "\n" for row in grid)
+
+
+def load_hotspot(O):
+    t = np.loadtxt(os.path.join(GOLDEN, KNOWN["hotspot_64"]["temp"]), dtype=np.float32).reshape(64, 64)
+    p = np.loadtxt(os.path.join(GOLDEN, KNOWN["hotspot_64"]["power"]), dtype=np.float32).reshape(64, 64)
+    cells = np.zeros((64, 64), dtype=O.HOTSPOT_CELL)
+    cells["temp"], cells["power"] = t, p
+    return cells
+
+
+def test_conway_known_answers(oracle):
+    g = load_conway()
+    assert int(g.sum()) == KNOWN["conway"]["live_cells"]["0"]
+    for n, md5 in KNOWN["conway"]["stdout_md5"].items():
+        out = oracle.conway(g, int(n))
+        assert hashlib.md5(conway_stdout(out).encode()).hexdigest() == md5
+    assert int(oracle.conway(g, 100).sum()) == KNOWN["conway"]["live_cells"]["100"]
+
+
+@pytest.mark.parametrize("case", KNOWN["jacobi5general"], ids=lambda c: f"{c['n']}x{c['iterations']}")
+def test_jacobi_known_answers(oracle, case):
+    n = case["n"]
+    if case.get("fma_build"):
+        if not oracle.cpu_has_fma():
+            pytest.skip("known answer from an FMA build; this CPU has no FMA")
+        with oracle.use_fma_build():
+            out = oracle.jacobi("Jacobi5General", case["coef"], oracle.jacobi_init(n, n), case["iterations"], n_threads=8)
+        plain = oracle.jacobi("Jacobi5General", case["coef"], oracle.jacobi_init(n, n), case["iterations"], n_threads=8)
+        assert np.abs(plain.view(np.int32).astype(np.int64) - out.view(np.int32)).max() <= 64  # a few ulp
+    else:
+        out = oracle.jacobi("Jacobi5General", case["coef"], oracle.jacobi_init(n, n), case["iterations"], n_threads=8)
+    assert abs(out.astype(np.float64).sum() - case["sum"]) <= 5e-7 * case["sum"]
+    for where, value in case["at"].items():
+        r, c = map(int, where.split(","))
+        assert out[r, c] == np.float32(value)
+
+
+def test_hotspot_known_answers(oracle):
+    cells = load_hotspot(oracle)
+    out = oracle.hotspot(oracle.hotspot_params(64, 64), cells, KNOWN["hotspot_64"]["iterations"])
+    lines = [f"{i}\t{v:g}" for i, v in enumerate(out["temp"].reshape(-1)[:3])]
+    assert lines == KNOWN["hotspot_64"]["first_output_lines"]
+    assert np.array_equal(out["power"], cells["power"])
+
+
+@pytest.mark.parametrize("case", KNOWN["selfcheck_cases"], ids=str)
+@pytest.mark.parametrize("radius", [1, 2])
+def test_selfcheck_known_answer(oracle, case, radius):
+    H, W, offset, n = case
+    out = oracle.selfcheck(radius, oracle.selfcheck_input(H, W, offset), offset, n)
+    # tests/StencilUpdateTest.hpp:53-62
+    assert (out["r"] == np.arange(H)[:, None]).all() and (out["c"] == np.arange(W)[None, :]).all()
+    assert (out["i_iteration"] == offset + n).all() and (out["i_subiteration"] == 0).all()
+    assert (out["status"] == 0).all()
+
+
+def test_selfcheck_detects_wrong_halo(oracle):
+    # the function must poison cells when the machinery is wrong: feed a wrong iteration index
+    out = oracle.selfcheck(1, oracle.selfcheck_input(16, 16, 3), 4, 1)
+    assert (out["status"] == 1).all()
+
+
+def test_zero_iterations_and_empty(oracle):
+    g = np.random.default_rng(1).random((5, 7), dtype=np.float32)
+    assert np.array_equal(oracle.jacobi("Jacobi5General", [0.2] * 5, g, 0), g)
+    e = np.zeros((0, 7), dtype=np.float32)
+    assert oracle.jacobi("Jacobi5General", [0.2] * 5, e, 3).shape == (0, 7)
+
+
+def test_halo_is_reimposed_every_sweep(oracle):
+    # 1x1 grid, Jacobi4Constant: (N+W+S+E)/4 with halo 2.0 stays 2.0 from the first generation on
+    g = np.array([[7.0]], dtype=np.float32)
+    for n in (1, 2, 5):
+        assert oracle.jacobi("Jacobi4Constant", [], g, n, halo=2.0)[0, 0] == np.float32(2.0)
+
+
+def test_iteration_offset_is_a_resume(oracle):
+    # running 3+4 generations with an offset equals 7 generations (selfcheck verifies indices itself)
+    a = oracle.selfcheck(1, oracle.selfcheck_input(20, 33, 10), 10, 3)
+    b = oracle.selfcheck(1, a, 13, 4)
+    c = oracle.selfcheck(1, oracle.selfcheck_input(20, 33, 10), 10, 7)
+    assert np.array_equal(b, c) and (c["status"] == 0).all()
+
+
+def test_threads_do_not_change_results(oracle):
+    g = np.random.default_rng(2).random((67, 129), dtype=np.float32)
+    a = oracle.jacobi("Jacobi9General", np.linspace(0.05, 0.2, 9), g, 6, n_threads=1)
+    b = oracle.jacobi("Jacobi9General", np.linspace(0.05, 0.2, 9), g, 6, n_threads=8)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_hotspot_against_rodinia_openmp(oracle, tmp_path):
+    """Second opinion from the reference tree: examples/hotspot/hotspot_openmp.cpp (third-party
+    Rodinia code, different operation order) built unchanged into oracle/_ref."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "hotspot_openmp")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/hotspot_openmp not built (reference tree absent)")
+    out_file = tmp_path / "out.txt"
+    subprocess.check_call(
+        [exe, "64", "64", "100", "4", os.path.join(GOLDEN, "hotspot_temp_64.txt"),
+         os.path.join(GOLDEN, "hotspot_power_64.txt"), str(out_file)],
+        stdout=subprocess.DEVNULL,
+    )
+    ref = np.loadtxt(out_file, dtype=np.float64)[:, 1].reshape(64, 64)
+    out = oracle.hotspot(oracle.hotspot_params(64, 64), load_hotspot(oracle), 100)["temp"]
+    assert np.abs(out.astype(np.float64) - ref).max() <= 2 * KNOWN["hotspot_64"]["rodinia_openmp_max_abs_diff"]

@@ -1,0 +1,262 @@
+"""Parity of the HIP sweeps (through the C ABI) against the CPU oracle on a real MI355X.
+
+Bit-exact for every application: integer/byte cells by nature, fp32 cells because both sides are
+built with -ffp-contract=off and evaluate the reference's expressions in the reference's order."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+KNOWN = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def run_hip(tf, grid, n, halo=None, offset=0):
+    from stencilstream_amd import update as U
+
+    su = U.StencilUpdate(U.Params(tf, halo_value=halo, iteration_offset=offset, n_iterations=n, blocking=True))
+    out = su(U.Grid.from_numpy(grid)).to_numpy()
+    assert su.get_n_processed_cells() == n * grid.shape[0] * grid.shape[1]
+    return out
+
+
+SHAPES = [(1, 1), (1, 70), (70, 1), (2, 3), (64, 64), (32, 64), (64, 32), (257, 511), (300, 1000), (1000, 300)]
+ITERS = [0, 1, 2, 3, 5, 8, 13, 29]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=str)
+def test_jacobi5general_bit_exact(gpu, oracle, shape):
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(0x5EED + shape[0] * 7 + shape[1])
+    grid = rng.random(shape, dtype=np.float32)
+    coef = [0.11, 0.19, 0.23, 0.31, 0.16]
+    for n in ITERS:
+        got = run_hip(U.jacobi("Jacobi5General", coef), grid, n, halo=np.float32(0.25))
+        want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=0.25, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"n={n}"
+
+
+@pytest.mark.parametrize("variant,ncoef", [("Jacobi1General", 1), ("Jacobi2Constant", 0), ("Jacobi3Constant", 0),
+                                           ("Jacobi4Constant", 0), ("Jacobi5Constant", 0), ("Jacobi4General", 4),
+                                           ("Jacobi9General", 9)])
+def test_jacobi_variants_bit_exact(gpu, oracle, variant, ncoef):
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(11)
+    grid = rng.random((190, 333), dtype=np.float32)
+    coef = list(rng.random(ncoef, dtype=np.float32) * 0.2)
+    for n in (1, 7, 16):
+        got = run_hip(U.jacobi(variant, coef), grid, n, halo=np.float32(0.5))
+        want = oracle.jacobi(variant, coef, grid, n, halo=0.5, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"{variant} n={n}"
+
+
+@pytest.mark.parametrize("case", KNOWN["jacobi5general"][:2], ids=lambda c: f"{c['n']}x{c['iterations']}")
+def test_jacobi_known_answers_on_gpu(gpu, oracle, case):
+    from stencilstream_amd import update as U
+
+    n = case["n"]
+    got = run_hip(U.jacobi("Jacobi5General", case["coef"]), oracle.jacobi_init(n, n), case["iterations"],
+                  halo=np.float32(0.0))
+    assert abs(got.astype(np.float64).sum() - case["sum"]) <= 5e-7 * case["sum"]
+    for where, value in case["at"].items():
+        r, c = map(int, where.split(","))
+        assert got[r, c] == np.float32(value)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (64, 64), (130, 257), (512, 512), (100, 1100)], ids=str)
+def test_conway_bit_exact(gpu, oracle, shape):
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(0xC0FFEE + shape[1])
+    grid = (rng.random(shape) < 0.35).astype(np.uint8)
+    for n in (1, 2, 9, 24, 100):
+        assert np.array_equal(run_hip(U.conway(), grid, n), oracle.conway(grid, n, n_threads=8)), f"n={n}"
+
+
+def test_conway_gosper_gun_known_answer(gpu):
+    """BASELINE config 0 input: the reference's 64x64 start pattern, md5 of the printed grid."""
+    from stencilstream_amd import update as U
+
+    chars = [ch for ch in open(os.path.join(GOLDEN, KNOWN["conway"]["input"])).read() if ch in "X."]
+    grid = (np.array(chars) == "X").astype(np.uint8).reshape(64, 64)
+    for n, md5 in KNOWN["conway"]["stdout_md5"].items():
+        out = run_hip(U.conway(), grid, int(n))
+        text = "".join("".join("X" if v else "." for v in row) + "\n" for row in out)
+        assert hashlib.md5(text.encode()).hexdigest() == md5
+
+
+@pytest.mark.parametrize("split", [True, False], ids=["soa", "aos"])
+@pytest.mark.parametrize("shape", [(64, 64), (1, 9), (9, 1), (200, 517), (600, 260)], ids=str)
+def test_hotspot_bit_exact(gpu, oracle, shape, split):
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(5 + shape[0])
+    cells = np.zeros(shape, dtype=U.HOTSPOT_CELL)
+    cells["temp"] = 320 + 10 * rng.random(shape, dtype=np.float32)
+    cells["power"] = rng.random(shape, dtype=np.float32) * 0.01
+    p = oracle.hotspot_params(*shape)
+    tf = U.hotspot(p.Rx_1, p.Ry_1, p.Rz_1, p.Cap_1, split_cell_structure=split)
+    for n in (1, 4, 11, 40):
+        got = run_hip(tf, cells, n)
+        want = oracle.hotspot(p, cells, n, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"n={n}"
+
+
+def test_hotspot_reference_input_known_answer(gpu, oracle):
+    from stencilstream_amd import update as U
+
+    t = np.loadtxt(os.path.join(GOLDEN, KNOWN["hotspot_64"]["temp"]), dtype=np.float32).reshape(64, 64)
+    pw = np.loadtxt(os.path.join(GOLDEN, KNOWN["hotspot_64"]["power"]), dtype=np.float32).reshape(64, 64)
+    cells = np.zeros((64, 64), dtype=U.HOTSPOT_CELL)
+    cells["temp"], cells["power"] = t, pw
+    p = oracle.hotspot_params(64, 64)
+    out = run_hip(U.hotspot(p.Rx_1, p.Ry_1, p.Rz_1, p.Cap_1), cells, KNOWN["hotspot_64"]["iterations"])
+    lines = [f"{i}\t{v:g}" for i, v in enumerate(out["temp"].reshape(-1)[:3])]
+    assert lines == KNOWN["hotspot_64"]["first_output_lines"]
+
+
+@pytest.mark.parametrize("name,radius,split", [("aos", 1, False), ("soa", 1, True), ("r2", 2, False)])
+@pytest.mark.parametrize("case", KNOWN["selfcheck_cases"] + [[37, 301, 5, 9], [301, 37, 0, 3]], ids=str)
+def test_selfcheck_known_answer(gpu, oracle, case, name, radius, split):
+    """The reference's own hot-path test (tests/cuda/StencilUpdate.cpp:30-50): the transition
+    function verifies halo, coordinates, iteration, sub-iteration and TDV of everything it sees."""
+    from stencilstream_amd import update as U
+
+    H, W, offset, n = case
+    halo = np.zeros((), dtype=U.SELFCHECK_CELL)
+    halo["status"] = 2
+    out = run_hip(U.selfcheck(radius, split), oracle.selfcheck_input(H, W, offset), n, halo=halo, offset=offset)
+    assert (out["status"] == 0).all(), "a cell saw a wrong neighbour, index or TDV"
+    assert (out["r"] == np.arange(H)[:, None]).all() and (out["c"] == np.arange(W)[None, :]).all()
+    assert (out["i_iteration"] == offset + n).all() and (out["i_subiteration"] == 0).all()
+    assert np.array_equal(bits(out), bits(oracle.selfcheck(radius, oracle.selfcheck_input(H, W, offset), offset, n)))
+
+
+def fdtd_setup(oracle, H, W):
+    from stencilstream_amd import capi
+
+    # parameters in the range of examples/fdtd/experiments/default.json, source off-centre
+    kw = dict(dt=8.3e-18, t_0=3e-13 * 0.01, tau=1e-13 * 0.01, omega=7.5e14, cutoff_iteration=40,
+              detect_iteration=10, source_radius_squared=36.0, source_r=H / 2.0 + 3, source_c=W / 2.0 - 2,
+              source_distance_bound=0.0, double_center_rc=float(H))
+    kw["source_distance_bound"] = 36.0 - (kw["source_c"] ** 2 + kw["source_r"] ** 2)
+    po, pc = oracle.FdtdParams(), capi.FdtdParams()
+    for k, v in kw.items():
+        setattr(po, k, v)
+        setattr(pc, k, v)
+    rng = np.random.default_rng(3)
+    cells = np.zeros((H, W), dtype=oracle.FDTD_CELL)
+    for f in ("ex", "ey", "hz"):
+        cells[f] = (rng.random((H, W), dtype=np.float32) - 0.5) * 1e-3
+    inside = ((np.arange(H)[:, None] - H / 2) ** 2 + (np.arange(W)[None, :] - W / 2) ** 2) < (min(H, W) * 0.4) ** 2
+    cells["ca"] = np.where(inside, 1.0, 1.0).astype(np.float32)
+    cells["cb"] = np.where(inside, 0.31, 0.0).astype(np.float32)
+    cells["da"] = np.where(inside, 1.0, 1.0).astype(np.float32)
+    cells["db"] = np.where(inside, 0.29, 0.0).astype(np.float32)
+    return po, pc, cells
+
+
+@pytest.mark.parametrize("split", [True, False], ids=["soa", "aos"])
+@pytest.mark.parametrize("shape", [(162, 162), (40, 333)], ids=str)
+def test_fdtd_bit_exact(gpu, oracle, shape, split):
+    from stencilstream_amd import update as U
+
+    po, pc, cells = fdtd_setup(oracle, *shape)
+    halo = np.zeros((), dtype=U.FDTD_CELL)
+    for n, offset in ((1, 0), (7, 0), (30, 5), (25, 30)):
+        got = run_hip(U.fdtd(pc, split), cells, n, halo=halo, offset=offset)
+        want = oracle.fdtd(po, cells, n, iteration_offset=offset, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"n={n} offset={offset}"
+    assert np.abs(want["hz_sum"]).max() > 0 and np.abs(want["hz"]).max() > 0
+
+
+def test_sweep_row_ranges_compose(gpu, oracle):
+    """ststhip_app_sweep on row bands with ghost rows (the multi-GPU building block): three strips
+    with emulated ghost exchange equal the whole-grid result."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    H, W, T = 230, 410, 4
+    rng = np.random.default_rng(8)
+    grid = rng.random((H, W), dtype=np.float32)
+    coef = [0.2, 0.21, 0.19, 0.22, 0.18]
+    p = capi.JacobiParams()
+    for i, c in enumerate(coef):
+        p.coef[i] = c
+    info = capi.app_info("jacobi5general")
+    g = T * info.halo_depth_per_generation
+    bounds = [0, 70, 150, H]
+    whole = torch.from_numpy(grid).cuda()
+    n_steps = 3
+    for _ in range(n_steps):
+        nxt = torch.empty_like(whole)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            lo, hi = max(0, a - g), min(H, b + g)
+            src = whole[lo:hi].contiguous()  # owned rows + ghost rows
+            dst = torch.full_like(src, float("nan"))
+            dom = capi.Domain(H, W, lo, hi - lo, W)
+            capi.app_sweep("jacobi5general", p, np.float32(0.0).tobytes(), dom, [src.data_ptr()], [dst.data_ptr()],
+                           a, b, 0, T, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.isnan(dst[: a - lo]).all() and torch.isnan(dst[b - lo:]).all(), "rows outside the range touched"
+            nxt[a:b] = dst[a - lo:b - lo]
+        whole = nxt
+    want = oracle.jacobi("Jacobi5General", coef, grid, T * n_steps, halo=0.0, n_threads=8)
+    assert np.array_equal(bits(whole.cpu().numpy()), bits(want))
+
+
+def test_scatter_gather_round_trip(gpu):
+    import torch
+
+    from stencilstream_amd import capi, update as U
+
+    rng = np.random.default_rng(4)
+    for dt, n_cells in ((U.FDTD_CELL, 70001), (U.SELFCHECK_CELL, 513), (U.HOTSPOT_CELL, 256)):
+        raw = rng.integers(0, 255, size=n_cells * dt.itemsize, dtype=np.uint8)
+        aos = torch.from_numpy(raw).cuda()
+        offs = [dt.fields[n][1] for n in dt.names]
+        sizes = [dt.fields[n][0].itemsize for n in dt.names]
+        planes = [torch.zeros(n_cells * s, dtype=torch.uint8, device="cuda") for s in sizes]
+        s = torch.cuda.current_stream().cuda_stream
+        capi.scatter_fields(aos.data_ptr(), dt.itemsize, n_cells, offs, sizes, [t.data_ptr() for t in planes], s)
+        host = raw.view(dt)
+        for name, t in zip(dt.names, planes):
+            assert np.array_equal(t.cpu().numpy().view(dt.fields[name][0]), host[name])
+        back = torch.zeros_like(aos)
+        capi.gather_fields(back.data_ptr(), dt.itemsize, n_cells, offs, sizes, [t.data_ptr() for t in planes], s)
+        assert torch.equal(back, aos)
+
+
+def test_invalid_arguments_are_rejected(gpu):
+    import torch
+
+    from stencilstream_amd import capi
+
+    a = torch.zeros(64 * 64, device="cuda")
+    b = torch.zeros(64 * 64, device="cuda")
+    p = capi.JacobiParams()
+    halo = np.float32(0).tobytes()
+    with pytest.raises(capi.StsthipError):  # ghost rows missing
+        capi.app_sweep("jacobi5general", p, halo, capi.Domain(128, 64, 32, 64, 64), [a.data_ptr()], [b.data_ptr()],
+                       32, 96, 0, 4)
+    with pytest.raises(capi.StsthipError):  # depth not compiled
+        capi.app_sweep("jacobi5general", p, halo, capi.Domain(64, 64, 0, 64, 64), [a.data_ptr()], [b.data_ptr()],
+                       0, 64, 0, 3)
+    with pytest.raises(capi.StsthipError):  # in-place
+        capi.app_sweep("jacobi5general", p, halo, capi.Domain(64, 64, 0, 64, 64), [a.data_ptr()], [a.data_ptr()],
+                       0, 64, 0, 1)
+    with pytest.raises(capi.StsthipError):  # pitch < width
+        capi.app_sweep("jacobi5general", p, halo, capi.Domain(64, 64, 0, 64, 32), [a.data_ptr()], [b.data_ptr()],
+                       0, 64, 0, 1)
