@@ -3,14 +3,13 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 torch.distributed.run with one rank per GPU.  A "step" is one StencilUpdate call of
-`--generations` generations (default 100, so the default 10 steps are BASELINE.json's 1000
-generations).  Rank 0 prints ONE JSON line.
+`--generations` generations (default 200, so the default 5 steps are BASELINE.json's 1000
+generations; 200 = 25 launches of 8 generations).  Rank 0 prints ONE JSON line.
 
 Metric: Gcell-updates/s = H*W*generations / time (sub-iterations not counted), the reference's
 definition (scripts/benchmark-common.jl:97-98,122).  The grid is resident in HBM before the timed
-region starts.  N > 1: the 16384*N/... see DESIGN.md -- weak scaling over row strips: every rank
-owns a 16384-row strip of a (16384*N) x 16384 grid and exchanges ghost rows with its neighbours
-over RCCL once per launch.
+region starts.  N > 1 is weak scaling over row strips: every rank owns a 16384-row strip of a
+(16384*N) x 16384 grid and exchanges ghost rows with its neighbours over RCCL once per launch.
 """
 import argparse
 import json
@@ -30,13 +29,13 @@ COEF = [0.2, 0.2, 0.2, 0.2, 0.2]  # examples/jacobi/scripts/benchmark.jl:44-45
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=16384, help="grid rows (per GPU) and columns")
-    ap.add_argument("--generations", type=int, default=100, help="generations per step")
+    ap.add_argument("--generations", type=int, default=200, help="generations per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-size", type=int, default=4096)
-    ap.add_argument("--cpu-generations", type=int, default=4)
+    ap.add_argument("--cpu-size", type=int, default=8192)
+    ap.add_argument("--cpu-generations", type=int, default=16)
     return ap.parse_args()
 
 
@@ -85,7 +84,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     capi.init(local_rank)
-    stream = torch.cuda.current_stream(device)
+    stream = torch.cuda.Stream(device)  # the stream every sweep is launched on (and timed on)
 
     H, W, gens = args.size, args.size, args.generations
     p = capi.JacobiParams()
@@ -98,6 +97,7 @@ def main():
         src = init_grid_device(torch, H, W, 0, H, device)
         dst = torch.empty_like(src)
         dom = capi.Domain(H, W, 0, H, W)
+        torch.cuda.synchronize()  # the grid is resident before anything runs on `stream`
 
         def step():
             return capi.app_run("jacobi5general", p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens,

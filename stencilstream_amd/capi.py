@@ -106,6 +106,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7 / libhsa-runtime64.so.1; importing it first makes the
+    # loader resolve this library's HIP dependency to that same copy (one HIP runtime per process,
+    # so torch tensors, streams and events are valid here).  A C++ host uses the system runtime.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -195,6 +200,39 @@ def list_apps():
         check(lib.ststhip_app_info_at(i, C.byref(info)), "ststhip_app_info_at")
         out.append(info.name.decode())
     return out
+
+
+_side_streams = {}
+
+
+class on_stream:
+    """Pick the HIP stream the library should use for work on torch tensors of `device`.
+
+    torch's default stream has handle 0, which this library reads as "use the runtime's own
+    stream"; instead a dedicated torch stream is used and ordered after/before the current one."""
+
+    def __init__(self, device):
+        import torch
+
+        self.torch = torch
+        self.device = device
+        self.current = torch.cuda.current_stream(device)
+        if self.current.cuda_stream != 0:
+            self.stream = self.current
+        else:
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device)
+            self.stream = _side_streams[key]
+
+    def __enter__(self):
+        if self.stream is not self.current:
+            self.stream.wait_stream(self.current)
+        return self.stream
+
+    def __exit__(self, *exc):
+        if self.stream is not self.current:
+            self.current.wait_stream(self.stream)
 
 
 def _ptr_array(pointers):

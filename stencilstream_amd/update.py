@@ -160,8 +160,19 @@ class StencilUpdate:
         if p.n_iterations == 0:
             return source  # handle onto the same cells, as the reference's AoS path
         capi.init(source.device.index if source.device.index is not None else -1)
-        stream = torch.cuda.current_stream(source.device).cuda_stream
         started = time.perf_counter()
+        with capi.on_stream(source.device) as torch_stream:
+            result, run = self._run(source, torch_stream)
+        self.walltime += time.perf_counter() - started
+        self.kernel_runtime += run.kernel_time_s
+        self.n_processed_cells += p.n_iterations * source.height * source.width
+        return result
+
+    def _run(self, source, torch_stream):
+        p = self.params
+        tf = p.transition_function
+        info = self.info
+        stream = torch_stream.cuda_stream
 
         result = source.make_similar()
         dom = source.domain()
@@ -183,9 +194,9 @@ class StencilUpdate:
                                blocking=False, profiling=p.profiling, stream=stream)
             capi.gather_fields(result.cells.data_ptr(), info.cell_size, n_cells, offsets, sizes,
                                [t.data_ptr() for t in b], stream)
+            for t in a + b:
+                t.record_stream(torch_stream)
             if p.blocking:
-                torch.cuda.current_stream(source.device).synchronize()
-        self.walltime += time.perf_counter() - started
-        self.kernel_runtime += run.kernel_time_s
-        self.n_processed_cells += p.n_iterations * n_cells
-        return result
+                torch_stream.synchronize()
+        result.cells.record_stream(torch_stream)
+        return result, run

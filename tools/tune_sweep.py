@@ -28,9 +28,11 @@ def main():
     dst = torch.empty_like(src)
     dom = capi.Domain(size, size, 0, size, size)
     halo = np.float32(0).tobytes()
-    stream = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    stream = side.cuda_stream
+    torch.cuda.synchronize()
     depths = [t for t in (1, 2, 4, 8) if t <= info.max_generations]
-    for T, wpc in itertools.product(depths, (4, 8, 16, 32)):
+    for T, wpc in itertools.product(depths, (8, 16, 32, 64, 128)):
         os.environ["STSTHIP_MAX_GENERATIONS"] = str(T)
         os.environ["STSTHIP_WAVES_PER_CU"] = str(wpc)
         capi.app_run(app, p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens, blocking=True, stream=stream)
