@@ -1,0 +1,173 @@
+"""Row-strip domain decomposition of one grid over the GPUs of a node, one process per GPU.
+
+New functionality relative to the reference (it has no spatial decomposition, SURVEY.md section
+8e); the semantics are those of a single StencilUpdate on the whole grid.
+
+Every rank owns `rows_owned` consecutive rows and keeps them in a buffer with `g_max` ghost rows on
+each side.  One pass = one kernel launch of T generations (temporal blocking) and consumes
+g = T * radius * n_subiterations ghost rows per side, so ghosts are exchanged once per pass:
+
+    comm stream   : wait(boundary rows of pass p-1) -> send/recv g rows with rank-1 / rank+1 (RCCL p2p over xGMI)
+    compute stream: wait(ghosts of pass p) -> boundary bands of pass p -> [event] -> interior of pass p
+
+so the exchange for pass p+1 runs concurrently with the interior sweep of pass p.  There is no
+collective on the data path.  The sweep itself is libststhip.so (ststhip_app_sweep); tests inject a
+CPU sweep to exercise this logic with the gloo backend.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+def split_rows(total_rows, world):
+    """Row range [begin, end) of every rank: as even as possible, earlier ranks get the remainder."""
+    base, extra = divmod(total_rows, world)
+    bounds, at = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        bounds.append((at, at + n))
+        at += n
+    return bounds
+
+
+def pass_depths(n_generations, max_generations):
+    """Greedy powers of two, largest first (the depths the sweep kernels are compiled for)."""
+    out, remaining = [], int(n_generations)
+    while remaining > 0:
+        t = int(max_generations)
+        while t > 1 and t > remaining:
+            t //= 2
+        out.append(t)
+        remaining -= t
+    return out
+
+
+class HipSweep:
+    """Default sweep backend: the HIP kernels behind the C ABI."""
+
+    def __init__(self, app, tf_params, halo_bytes):
+        self.app, self.tf_params, self.halo_bytes = app, tf_params, halo_bytes
+        info = capi.app_info(app)
+        self.n_planes = info.n_planes
+        self.plane_elem_size = [info.plane_elem_size[i] for i in range(info.n_planes)]
+        self.max_generations = info.max_generations
+        self.halo_per_generation = info.halo_depth_per_generation
+
+    def __call__(self, src, dst, dom, out_begin, out_end, iteration, depth, stream):
+        capi.app_sweep(self.app, self.tf_params, self.halo_bytes, dom, [t.data_ptr() for t in src],
+                       [t.data_ptr() for t in dst], out_begin, out_end, iteration, depth,
+                       stream.cuda_stream if stream is not None else 0)
+
+
+class StripDomain:
+    """The rows of one rank plus ghost rows, double buffered."""
+
+    def __init__(self, app, tf_params, halo_bytes, total_rows, width, rank, world, device, cell_dtype=None,
+                 sweep=None, group=None, min_rows_check=True):
+        self.sweep = sweep if sweep is not None else HipSweep(app, tf_params, halo_bytes)
+        self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
+        self.total_rows, self.width = int(total_rows), int(width)
+        self.bounds = split_rows(self.total_rows, world)
+        self.row_begin, self.row_end = self.bounds[rank]
+        self.g_max = self.sweep.max_generations * self.sweep.halo_per_generation
+        if min_rows_check and world > 1 and min(b - a for a, b in self.bounds) < 2 * self.g_max:
+            raise ValueError("strips are thinner than two halo depths; use fewer ranks or a larger grid")
+        self.row_origin = self.row_begin - self.g_max
+        self.local_rows = (self.row_end - self.row_begin) + 2 * self.g_max
+        self.on_gpu = self.device.type == "cuda"
+        self.planes = [
+            [torch.zeros((self.local_rows, self.width * es), dtype=torch.uint8, device=self.device)
+             for es in self.sweep.plane_elem_size]
+            for _ in range(2)
+        ]
+        self.current = 0
+        if self.on_gpu:
+            self.compute_stream = torch.cuda.Stream(self.device)
+            self.comm_stream = torch.cuda.Stream(self.device)
+        else:
+            self.compute_stream = self.comm_stream = None
+        self.dom = capi.Domain(self.total_rows, self.width, self.row_origin, self.local_rows, self.width)
+        self.n_launches = 0
+
+    # ---- data in / out -------------------------------------------------------------------
+    def _owned_slice(self):
+        return slice(self.row_begin - self.row_origin, self.row_end - self.row_origin)
+
+    def load_owned(self, *plane_rows):
+        """Set the owned rows from one 2-D tensor per plane (any dtype of the right row size)."""
+        for dst, rows in zip(self.planes[self.current], plane_rows):
+            raw = rows.contiguous().view(torch.uint8).reshape(rows.shape[0], -1)
+            dst[self._owned_slice()].copy_(raw)
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def owned(self, plane=0, dtype=torch.float32):
+        if self.on_gpu:
+            self.compute_stream.synchronize()
+        return self.planes[self.current][plane][self._owned_slice()].view(dtype)
+
+    # ---- ghost exchange ------------------------------------------------------------------
+    def _exchange(self, planes, g):
+        """Fill the g ghost rows next to the owned rows of `planes` from the neighbours."""
+        if self.world == 1 or g == 0:
+            return
+        o = self._owned_slice()
+        ops = []
+        up, down = self.rank - 1, self.rank + 1
+        for p in planes:
+            if up >= 0:
+                ops.append(dist.P2POp(dist.isend, p[o.start:o.start + g], self._peer(up), self.group))
+                ops.append(dist.P2POp(dist.irecv, p[o.start - g:o.start], self._peer(up), self.group))
+            if down < self.world:
+                ops.append(dist.P2POp(dist.isend, p[o.stop - g:o.stop], self._peer(down), self.group))
+                ops.append(dist.P2POp(dist.irecv, p[o.stop:o.stop + g], self._peer(down), self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def _peer(self, strip_rank):
+        return strip_rank if self.group is None else dist.get_global_rank(self.group, strip_rank)
+
+    # ---- time stepping -------------------------------------------------------------------
+    def advance(self, iteration_offset, n_generations):
+        """Advance the whole (distributed) grid by n_generations generations."""
+        depths = pass_depths(n_generations, self.sweep.max_generations)
+        iteration = int(iteration_offset)
+        a, b = self.row_begin, self.row_end
+        cs, ms = self.compute_stream, self.comm_stream
+
+        def exchange_for(planes, depth):
+            g = depth * self.sweep.halo_per_generation
+            if self.on_gpu:
+                with torch.cuda.stream(ms):
+                    self._exchange(planes, g)
+            else:
+                self._exchange(planes, g)
+
+        if depths:
+            if self.on_gpu:
+                ms.wait_stream(cs)
+            exchange_for(self.planes[self.current], depths[0])
+        for i, depth in enumerate(depths):
+            g = depth * self.sweep.halo_per_generation
+            src, dst = self.planes[self.current], self.planes[self.current ^ 1]
+            top_end, bot_begin = min(a + g, b), max(b - g, min(a + g, b))
+            if self.on_gpu:
+                cs.wait_stream(ms)  # ghosts of this pass have landed
+            # boundary bands first: the next exchange only needs these rows
+            self.sweep(src, dst, self.dom, a, top_end, iteration, depth, cs)
+            self.n_launches += 1
+            if bot_begin < b:
+                self.sweep(src, dst, self.dom, bot_begin, b, iteration, depth, cs)
+                self.n_launches += 1
+            if i + 1 < len(depths):
+                if self.on_gpu:
+                    ms.wait_stream(cs)
+                exchange_for(dst, depths[i + 1])  # overlaps with the interior sweep below
+            if top_end < bot_begin:
+                self.sweep(src, dst, self.dom, top_end, bot_begin, iteration, depth, cs)
+                self.n_launches += 1
+            self.current ^= 1
+            iteration += depth
+        return None

@@ -233,7 +233,7 @@ def test_scatter_gather_round_trip(gpu):
         capi.scatter_fields(aos.data_ptr(), dt.itemsize, n_cells, offs, sizes, [t.data_ptr() for t in planes], s)
         host = raw.view(dt)
         for name, t in zip(dt.names, planes):
-            assert np.array_equal(t.cpu().numpy().view(dt.fields[name][0]), host[name])
+            assert np.array_equal(t.cpu().numpy(), np.ascontiguousarray(host[name]).view(np.uint8)), name
         back = torch.zeros_like(aos)
         capi.gather_fields(back.data_ptr(), dt.itemsize, n_cells, offs, sizes, [t.data_ptr() for t in planes], s)
         assert torch.equal(back, aos)
@@ -260,3 +260,27 @@ def test_invalid_arguments_are_rejected(gpu):
     with pytest.raises(capi.StsthipError):  # pitch < width
         capi.app_sweep("jacobi5general", p, halo, capi.Domain(64, 64, 0, 64, 32), [a.data_ptr()], [b.data_ptr()],
                        0, 64, 0, 1)
+
+
+def test_strip_domain_single_rank_on_gpu(gpu, oracle):
+    """The distributed driver (streams, boundary-first order, ragged depths) with the real HIP sweep;
+    world_size 1 here, the multi-rank logic is covered by tests/test_dist_cpu.py."""
+    import torch
+
+    from stencilstream_amd import capi
+    from stencilstream_amd.dist import StripDomain
+
+    H, W = 300, 700
+    rng = np.random.default_rng(21)
+    grid = rng.random((H, W), dtype=np.float32)
+    coef = [0.2, 0.21, 0.19, 0.22, 0.18]
+    p = capi.JacobiParams()
+    for i, c in enumerate(coef):
+        p.coef[i] = c
+    strip = StripDomain("jacobi5general", p, np.float32(0).tobytes(), H, W, 0, 1, gpu)
+    strip.load_owned(torch.from_numpy(grid).to(gpu))
+    strip.advance(0, 13)
+    strip.advance(13, 8)
+    got = strip.owned(0, torch.float32).cpu().numpy()
+    want = oracle.jacobi("Jacobi5General", coef, grid, 21, halo=0.0, n_threads=8)
+    assert np.array_equal(bits(got), bits(want))
