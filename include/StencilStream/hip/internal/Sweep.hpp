@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <tuple>
 #include <type_traits>
+#include <utility>
 
 namespace stencil {
 namespace hip {
@@ -466,7 +467,7 @@ inline int pick_chunk_rows(int out_rows, unsigned n_strips, int halo_rows) {
         return std::min(forced, std::max(out_rows, 1));
     int cus = 256;
     ststhip_compute_units(&cus);
-    const long target_waves = long(cus) * env_int("STSTHIP_WAVES_PER_CU", 16);
+    const long target_waves = long(cus) * env_int("STSTHIP_WAVES_PER_CU", 32);
     long chunks = std::max<long>(1, target_waves / std::max(1u, n_strips));
     long rows = (out_rows + chunks - 1) / chunks;
     rows = std::max<long>(rows, 8L * halo_rows);
@@ -488,14 +489,7 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     if (dom.global_height >= (1ull << 31) || dom.global_width >= (1ull << 31))
         throw std::range_error("grid extents must be below 2^31 per dimension");
 
-    typename SW::Args args;
-    args.f = f;
-    args.halo = halo;
-    for (int t = 0; t < T; t++)
-        args.tdv[t] = tdv[t];
-    args.src = src;
-    args.dst = dst;
-    SweepGeometry &g = args.geo;
+    SweepGeometry g;
     g.grid_h = std::int32_t(dom.global_height);
     g.grid_w = std::int32_t(dom.global_width);
     g.row_origin = std::int32_t(dom.row_origin);
@@ -509,6 +503,11 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
     g.pitch = dom.pitch;
     g.iteration = iteration;
+
+    // transition functions need not be default-constructible: build the argument block in one go
+    typename SW::Args args = [&]<std::size_t... Is>(std::index_sequence<Is...>) {
+        return typename SW::Args{f, halo, {tdv[Is]...}, src, dst, g};
+    }(std::make_index_sequence<std::size_t(T)>{});
 
     const unsigned waves = g.n_strips * g.n_chunks;
     const unsigned waves_per_block = 4;

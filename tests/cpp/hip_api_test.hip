@@ -1,0 +1,87 @@
+// API tests of the MI355X backend through the C++ templates (hipcc, needs a GPU to run).
+// Also compiled: an *unannotated* user functor (no __device__), which is how applications written
+// for the reference look; it is device-callable because this file is built with --hipstdpar.
+#include "api_tests.hpp"
+#include <StencilStream/BaseTransitionFunction.hpp>
+#include <StencilStream/cuda/StencilUpdate.hpp>
+#include <apps/conway.hpp>
+
+using namespace stencil;
+
+static_assert(concepts::Grid<hip::Grid<bool>, bool>);
+static_assert(concepts::StencilUpdate<cuda::StencilUpdate<apps::Conway>, apps::Conway, cuda::Grid<bool>>);
+static_assert(std::is_same_v<cuda::Grid<float>, hip::Grid<float>>);
+
+// exactly what user code looks like: plain C++, no HIP annotations
+struct UserHeat : public BaseTransitionFunction {
+    using Cell = float;
+    float alpha;
+    float operator()(Stencil<float, 1> const &s) const {
+        return s[0][0] + alpha * (s[-1][0] + s[1][0] + s[0][-1] + s[0][1] - 4.0f * s[0][0]);
+    }
+};
+
+static void test_user_functor() {
+    const std::size_t h = 123, w = 517, n = 21;
+    using SU = cuda::StencilUpdate<UserHeat>;
+    SU::GridImpl grid(h, w);
+    std::vector<float> host(h * w);
+    {
+        SU::GridImpl::GridAccessor<sycl::access::mode::read_write> ac(grid);
+        for (std::size_t r = 0; r < h; r++)
+            for (std::size_t c = 0; c < w; c++)
+                host[r * w + c] = ac[r][c] = float((r * 31 + c * 17) % 101) / 101.0f;
+    }
+    SU update({.transition_function = UserHeat{.alpha = 0.1f},
+               .halo_value = 0.5f,
+               .n_iterations = n,
+               .blocking = true,
+               .profiling = true});
+    SU::GridImpl out = update(grid);
+    // host restatement of the same sweep
+    std::vector<float> next(h * w);
+    auto at = [&](std::vector<float> const &g, long r, long c) {
+        return (r < 0 || c < 0 || r >= long(h) || c >= long(w)) ? 0.5f : g[r * w + c];
+    };
+    for (std::size_t it = 0; it < n; it++) {
+        for (long r = 0; r < long(h); r++)
+            for (long c = 0; c < long(w); c++)
+                next[r * w + c] = at(host, r, c) + 0.1f * (at(host, r - 1, c) + at(host, r + 1, c) +
+                                                          at(host, r, c - 1) + at(host, r, c + 1) -
+                                                          4.0f * at(host, r, c));
+        host.swap(next);
+    }
+    SU::GridImpl::GridAccessor<sycl::access::mode::read> ac(out);
+    bool same = true;
+    for (std::size_t r = 0; r < h; r++)
+        for (std::size_t c = 0; c < w; c++)
+            same = same && ac[r][c] == host[r * w + c];
+    REQUIRE(same);
+    REQUIRE(update.get_kernel_runtime() > 0.0 && update.get_kernel_runtime() <= update.get_walltime());
+}
+
+static void test_zero_iterations_alias() {
+    hip::Grid<bool> g(4, 4);
+    hip::StencilUpdate<apps::Conway> update({.transition_function = apps::Conway(), .n_iterations = 0});
+    hip::Grid<bool> out = update(g);
+    {
+        hip::Grid<bool>::GridAccessor<sycl::access::mode::read_write> ac(out);
+        ac[1][1] = true;
+    }
+    hip::Grid<bool>::GridAccessor<sycl::access::mode::read> in(g);
+    REQUIRE(in[1][1] == true);
+}
+
+int main() {
+    api_tests::test_stencil_indexing();
+    api_tests::test_grid<hip::Grid<sycl::id<2>>>(128, 128);
+    api_tests::test_grid<hip::Grid<sycl::id<2>>>(3, 17);
+    // AoS and split cell structure, as tests/cuda/StencilUpdate.cpp:30-50
+    api_tests::test_stencil_update_cases<hip::Grid<apps::SelfCheckCell>,
+                                         hip::StencilUpdate<apps::SelfCheck<1>, false>>();
+    api_tests::test_stencil_update_cases<hip::Grid<apps::SelfCheckCell>,
+                                         hip::StencilUpdate<apps::SelfCheck<1>, true>>();
+    test_user_functor();
+    test_zero_iterations_alias();
+    return finish("hip_api_test");
+}

@@ -1,0 +1,27 @@
+"""Runs the C++ API test binaries (tests/cpp): the reference's unit tests of Stencil, Grid and
+StencilUpdate restated for stencil::cpu (host) and stencil::hip (MI355X, through the templates)."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+OUT = os.path.join(ROOT, "build", "tests")
+
+
+def test_host_api():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), os.path.join(OUT, "host_api_test")])
+    res = subprocess.run([os.path.join(OUT, "host_api_test")], capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stdout.decode() + res.stderr.decode()
+    assert b"0 failures" in res.stdout
+
+
+@pytest.mark.gpu
+def test_hip_api():
+    binary = os.path.join(OUT, "hip_api_test")
+    if not os.path.exists(binary):
+        pytest.fail("build/tests/hip_api_test missing: run __graft_entry__.build()")
+    res = subprocess.run([binary], capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stdout.decode() + res.stderr.decode()
+    assert b"0 failures" in res.stdout

@@ -1,0 +1,193 @@
+"""The reference's example applications, built UNCHANGED from the reference tree against this
+repository's headers (examples/Makefile -> build/examples/), run end to end.
+
+*_cpu binaries use stencil::cpu (host), *_hip binaries stencil::cuda == stencil::hip (MI355X).
+The binaries are build products (git-ignored); tests skip when they are absent (the reference tree
+only exists in the build container, the binaries travel to the GPU box)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+EX = os.path.join(ROOT, "build", "examples")
+KNOWN = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+
+
+def exe(name):
+    path = os.path.join(EX, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not built (needs the reference tree; run `make -C examples`)")
+    return path
+
+
+def run(cmd, **kw):
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    return subprocess.run(cmd, check=True, capture_output=True, env=env, timeout=600, **kw)
+
+
+def conway_text(grid):
+    return "".join("".join("X" if v else "." for v in row) + "\n" for row in grid)
+
+
+def conway_case(binary, grid, n):
+    out = run([binary, str(grid.shape[0]), str(grid.shape[1]), str(n)], input=conway_text(grid).encode()).stdout.decode()
+    rows = [line for line in out.splitlines() if line and set(line) <= {"X", "."}]
+    return (np.array([list(r) for r in rows]) == "X").astype(np.uint8)
+
+
+def gosper():
+    chars = [ch for ch in open(os.path.join(GOLDEN, KNOWN["conway"]["input"])).read() if ch in "X."]
+    return (np.array(chars) == "X").astype(np.uint8).reshape(64, 64)
+
+
+# ------------------------------------------------------------------ CPU backend (BASELINE config 0)
+def test_conway_cpu_known_answers():
+    binary = exe("conway_cpu")
+    for n, md5 in KNOWN["conway"]["stdout_md5"].items():
+        out = run([binary, "64", "64", n], input=open(os.path.join(GOLDEN, KNOWN["conway"]["input"]), "rb").read())
+        assert hashlib.md5(out.stdout).hexdigest() == md5
+
+
+def test_conway_cpu_512x512_100_generations(oracle):
+    """BASELINE.json configs[0]: 512x512, 100 generations, cpu backend, bit-exact."""
+    binary = exe("conway_cpu")
+    grid = np.zeros((512, 512), dtype=np.uint8)
+    grid[:64, :64] = gosper()  # the reference's input at the NW corner
+    assert np.array_equal(conway_case(binary, grid, 100), oracle.conway(grid, 100, n_threads=8))
+    # Bernoulli(0.35) from a fixed seed
+    rnd = (np.random.default_rng(0xC0FFEE).random((512, 512)) < 0.35).astype(np.uint8)
+    assert np.array_equal(conway_case(binary, rnd, 100), oracle.conway(rnd, 100, n_threads=8))
+
+
+def test_hotspot_cpu_reference_input(tmp_path, oracle):
+    binary = exe("hotspot_cpu")
+    out_file = tmp_path / "out.txt"
+    res = run([binary, "64", "64", "100", os.path.join(GOLDEN, "hotspot_temp_64.txt"),
+               os.path.join(GOLDEN, "hotspot_power_64.txt"), str(out_file)])
+    assert b"Walltime:" in res.stdout and b"GFlops:" in res.stdout
+    lines = open(out_file).read().splitlines()
+    assert lines[:3] == KNOWN["hotspot_64"]["first_output_lines"]
+    t = np.loadtxt(os.path.join(GOLDEN, "hotspot_temp_64.txt"), dtype=np.float32).reshape(64, 64)
+    p = np.loadtxt(os.path.join(GOLDEN, "hotspot_power_64.txt"), dtype=np.float32).reshape(64, 64)
+    cells = np.zeros((64, 64), dtype=oracle.HOTSPOT_CELL)
+    cells["temp"], cells["power"] = t, p
+    want = oracle.hotspot(oracle.hotspot_params(64, 64), cells, 100)["temp"].reshape(-1)
+    assert lines == [f"{i}\t{v:g}" for i, v in enumerate(want)]
+
+
+# ------------------------------------------------------------------ MI355X backend
+@pytest.mark.gpu
+def test_conway_hip(oracle):
+    binary = exe("conway_hip")
+    for n, md5 in KNOWN["conway"]["stdout_md5"].items():
+        out = run([binary, "64", "64", n], input=open(os.path.join(GOLDEN, KNOWN["conway"]["input"]), "rb").read())
+        assert hashlib.md5(out.stdout).hexdigest() == md5
+    rnd = (np.random.default_rng(0xC0FFEE).random((512, 512)) < 0.35).astype(np.uint8)
+    assert np.array_equal(conway_case(binary, rnd, 100), oracle.conway(rnd, 100, n_threads=8))
+
+
+JACOBI_COEFS = {"Jacobi1General": 1, "Jacobi2Constant": 0, "Jacobi3Constant": 0, "Jacobi4Constant": 0,
+                "Jacobi5Constant": 0, "Jacobi4General": 4, "Jacobi5General": 5, "Jacobi9General": 9}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", sorted(JACOBI_COEFS))
+def test_jacobi_hip_bit_exact(tmp_path, oracle, variant):
+    """examples/jacobi/jacobi.cpp unchanged: argv, centred-square init, raw fp32 output."""
+    binary = exe(f"jacobi_{variant}_hip")
+    n = JACOBI_COEFS[variant]
+    coef = [f"{0.2 - 0.01 * i:.4f}" for i in range(n)]
+    H, W, its = 300, 700, 29
+    out_file = tmp_path / "out.bin"
+    res = run([binary, str(H), str(W), str(its), str(out_file)] + coef)
+    assert b"Walltime:" in res.stdout
+    got = np.fromfile(out_file, dtype=np.float32).reshape(H, W)
+    want = oracle.jacobi(variant, [float(c) for c in coef], oracle.jacobi_init(H, W), its, halo=0.0, n_threads=8)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_jacobi_hip_show_config():
+    out = run([exe("jacobi_Jacobi5General_hip"), "show-config"]).stdout.decode()
+    cfg = json.loads(out)
+    assert cfg == {"variant": "cuda", "n_coefficients": 5, "n_operations": 9}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary_name", ["hotspot_hip", "hotspot_aos_hip"])
+def test_hotspot_hip_bit_exact(tmp_path, oracle, binary_name):
+    binary = exe(binary_name)
+    n, its = 256, 50
+    # synthetic inputs of examples/hotspot/data/input_gen.jl:3-15
+    temp = np.full((n, n), 30.0, dtype=np.float32)
+    power = np.zeros((n, n), dtype=np.float32)
+    lo, hi = n // 4 - 1, 3 * n // 4  # 1-based inclusive n/4 .. 3n/4
+    power[lo:hi, lo:hi] = 0.5
+    temp.tofile(tmp_path / "temp.bin")
+    power.tofile(tmp_path / "power.bin")
+    run([binary, str(n), str(n), str(its), str(tmp_path / "temp.bin"), str(tmp_path / "power.bin"),
+         str(tmp_path / "out.bin")])
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.float32).reshape(n, n)
+    cells = np.zeros((n, n), dtype=oracle.HOTSPOT_CELL)
+    cells["temp"], cells["power"] = temp, power
+    want = oracle.hotspot(oracle.hotspot_params(n, n), cells, its, n_threads=8)["temp"]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+FDTD_EXPERIMENT = {
+    "tau": 100e-15, "dx": 10e-9,
+    "time": {"t_cutoff": 0.2, "t_detect": 0.3, "t_max": 0.5, "t_snap": 0.2},
+    "source": {"frequency": 120e12, "phase": 0.1, "x": 30e-9, "y": -20e-9, "radius": 50e-9},
+    "cavity_rings": [{"radius": 400e-9, "mu_r": 11.56, "eps_r": 1.0, "sigma": 0.0},
+                     {"radius": 100e-9, "mu_r": 1.0, "eps_r": 2.0, "sigma": 0.0}],
+}
+
+
+@pytest.mark.gpu
+def test_fdtd_hip_equals_cpu_backend(tmp_path):
+    """examples/fdtd unchanged (coef resolver, snapshots => several update calls with
+    iteration_offset): every CSV the MI355X build writes equals the cpu-backend build's, text for text."""
+    hip_bin, cpu_bin = exe("fdtd_hip"), exe("fdtd_cpu")
+    cfg = tmp_path / "experiment.json"
+    cfg.write_text(json.dumps(FDTD_EXPERIMENT))
+    outs = {}
+    for name, binary in (("hip", hip_bin), ("cpu", cpu_bin)):
+        d = tmp_path / name
+        d.mkdir()
+        res = run([binary, "-c", str(cfg), "-o", str(d)])
+        assert b"n. timesteps      = 2142" in res.stdout and b"Walltime:" in res.stdout
+        outs[name] = {f: open(d / f).read() for f in sorted(os.listdir(d))}
+    assert sorted(outs["hip"]) == ["hz.1714.csv", "hz.2571.csv", "hz.857.csv", "hz_sum.2142.csv"]
+    assert outs["hip"] == outs["cpu"]
+    assert any(v != "0" for v in outs["hip"]["hz_sum.2142.csv"].replace("\n", ",").split(","))
+
+
+CONVECTION_EXPERIMENT = {"ly": 1.0, "lx": 3.0, "py": 0.5, "px": 1.5, "res": 32, "eta0": 1.0, "DcT": 1.0,
+                         "deltaT": 1.0, "Ra": 1e7, "Pra": 1e3, "iterMax": 400, "nt": 3, "nout": 1, "nerr": 100,
+                         "epsilon": 1e-4, "dmp": 2}
+
+
+@pytest.mark.gpu
+def test_convection_hip_matches_cpu_backend(tmp_path):
+    """examples/convection unchanged (fp64, 11-field cell, two transition functions, host-side
+    convergence check between update calls)."""
+    hip_bin, cpu_bin = exe("convection_hip"), exe("convection_cpu")
+    cfg = tmp_path / "experiment.json"
+    cfg.write_text(json.dumps(CONVECTION_EXPERIMENT))
+    frames = {}
+    for name, binary in (("hip", hip_bin), ("cpu", cpu_bin)):
+        d = tmp_path / name
+        d.mkdir()
+        res = run([binary, str(cfg), str(d)])
+        assert b"Total time" in res.stdout
+        frames[name] = {f: np.loadtxt(d / f, delimiter=",") for f in sorted(os.listdir(d))}
+    assert sorted(frames["hip"]) == sorted(frames["cpu"]) and frames["hip"]
+    for f in frames["hip"]:
+        a, b = frames["hip"][f], frames["cpu"][f]
+        assert a.shape == b.shape
+        assert np.allclose(a, b, rtol=1e-10, atol=1e-12), f
