@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <tuple>
@@ -168,7 +169,7 @@ template <int DppCtrl, typename T> STST_DEVICE inline T lane_shift(T const &valu
     __builtin_memcpy(&words, &value, sizeof(T));
 #pragma unroll
     for (int i = 0; i < n_words; i++)
-        words.w[i] = __builtin_amdgcn_update_dpp(0, words.w[i], DppCtrl, 0xf, 0xf, false);
+        words.w[i] = __builtin_amdgcn_update_dpp(0, words.w[i], DppCtrl, 0xf, 0xf, true);
     T shifted;
     __builtin_memcpy(&shifted, &words, sizeof(T));
     return shifted;
@@ -204,6 +205,7 @@ template <typename Cell, bool SOA> constexpr int cell_words() {
 //   max_generations (T)  deepest temporal blocking compiled (powers of two up to it are built)
 //   prefetch_rows (P)    rows loaded ahead; must be a multiple of 2*radius
 //   interior_variant     also build the check-free code path for waves away from the grid edge
+//   min_waves_per_simd   occupancy the register allocator must allow (second __launch_bounds__ argument)
 template <typename F, bool SOA> struct SweepTuning {
   private:
     static constexpr int R = int(F::stencil_radius);
@@ -234,6 +236,7 @@ template <typename F, bool SOA> struct SweepTuning {
     static constexpr int max_generations = pick_t(cells_per_lane);
     static constexpr int prefetch_rows = pick_p(cells_per_lane);
     static constexpr bool interior_variant = (W * NS <= 16);
+    static constexpr int min_waves_per_simd = 1;
 };
 
 namespace internal {
@@ -310,21 +313,25 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                 pre[u][k] = a.halo;
         });
 
+        // Rows outside [load_lo, y_load_end) are clamped into that range instead of being skipped: the
+        // load stays unconditional, so the compiler can count the loads in flight (s_waitcnt vmcnt(P-1)
+        // instead of vmcnt(0)).  A clamped row only feeds cells that lie outside the grid (replaced by
+        // the halo value below) or below the last row this wave has to produce.
         auto load_row = [&](const int y, Cell(&into)[K]) __attribute__((always_inline)) {
-            if (y >= g.load_lo && y < y_load_end) { // wave-uniform
-                const std::size_t first =
-                    std::size_t(y - g.row_origin) * g.pitch + std::size_t(std::int64_t(x0));
-                if constexpr (!EDGE) {
+            int yc = y < g.load_lo ? g.load_lo : y;
+            yc = yc < y_load_end ? yc : y_load_end - 1;
+            const std::size_t first =
+                std::size_t(yc - g.row_origin) * g.pitch + std::size_t(std::int64_t(x0));
+            if constexpr (!EDGE) {
+                a.src.template load<K>(first, into);
+            } else {
+                if (vec_in) {
                     a.src.template load<K>(first, into);
                 } else {
-                    if (vec_in) {
-                        a.src.template load<K>(first, into);
-                    } else {
 #pragma unroll
-                        for (int k = 0; k < K; k++)
-                            if (col_in[k])
-                                a.src.load_one(first + k, into[k]);
-                    }
+                    for (int k = 0; k < K; k++)
+                        if (col_in[k])
+                            a.src.load_one(first + k, into[k]);
                 }
             }
         };
@@ -403,6 +410,9 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                         win[lc][oldest][k] = cur[k];
                         cur[k] = next[k];
                     }
+#ifdef STST_LEVEL_BARRIER
+                    __builtin_amdgcn_sched_barrier(0); // keep levels from interleaving (register pressure)
+#endif
                 });
 
                 const int j = y - G; // row leaving the last level
@@ -448,8 +458,9 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
     }
 };
 
-template <typename SW>
-__global__ void __launch_bounds__(256) sweep_kernel(const typename SW::Args args) {
+// MIN_WAVES = waves per SIMD the register allocator must leave room for (launch-bounds semantics).
+template <typename SW, int MIN_WAVES = 1>
+__global__ void __launch_bounds__(256, MIN_WAVES) sweep_kernel(const typename SW::Args args) {
     SW::entry(args);
 }
 
@@ -459,20 +470,36 @@ inline int env_int(const char *name, int fallback) {
     return (v && *v) ? std::atoi(v) : fallback;
 }
 
-// Rows of output per wave: enough waves to fill the chip several times over, but chunks long
-// enough that the 2*G warm-up rows stay a small fraction.
-inline int pick_chunk_rows(int out_rows, unsigned n_strips, int halo_rows) {
+// Rows of output per wave.  A wave costs (rows + 2*G warm-up rows + prologue); the chip keeps
+// S = CUs * resident workgroups * 4 waves in flight and back-fills as waves retire, so
+//   time ~ waves * cost / S  +  alpha * cost      (alpha ~ 0.5: the ragged tail of the last waves)
+// with waves = strips * out_rows / rows.  Minimising over rows gives the closed form below: long
+// chunks waste the tail, short chunks waste warm-up rows.  (Measured optimum for Jacobi 16384^2,
+// T = 8: ~135 rows; the formula gives 133.)
+inline int pick_chunk_rows(int out_rows, unsigned n_strips, int halo_rows, int resident_blocks,
+                           int waves_per_block) {
     int forced = env_int("STSTHIP_CHUNK_ROWS", 0);
     if (forced > 0)
         return std::min(forced, std::max(out_rows, 1));
     int cus = 256;
     ststhip_compute_units(&cus);
-    const long target_waves = long(cus) * env_int("STSTHIP_WAVES_PER_CU", 32);
-    long chunks = std::max<long>(1, target_waves / std::max(1u, n_strips));
-    long rows = (out_rows + chunks - 1) / chunks;
-    rows = std::max<long>(rows, 8L * halo_rows);
-    rows = std::max<long>(rows, 16);
-    return int(std::min<long>(rows, std::max(out_rows, 1)));
+    const double slots = double(cus) * std::max(resident_blocks, 1) * waves_per_block;
+    const double alpha = env_int("STSTHIP_TAIL_PERMILLE", 500) / 1000.0;
+    const double overhead = 2.0 * halo_rows + 8.0;
+    double rows = std::sqrt(double(out_rows) * double(n_strips) * overhead / (alpha * slots));
+    rows = std::max(rows, 1.0);
+    long chunks = std::max<long>(1, long(double(out_rows) / rows + 0.5));
+    // snap to a whole number of residency rounds (just below it) when that is a small change:
+    // a launch of k*S + a few waves pays for a nearly empty extra round
+    const double rounds = double(chunks) * n_strips / slots;
+    if (rounds >= 0.75) {
+        const long k = std::max<long>(1, long(rounds + 0.5));
+        const long snapped = long(k * slots) / long(std::max(1u, n_strips));
+        if (snapped >= 1 && snapped * 4 >= chunks * 3 && snapped * 4 <= chunks * 5)
+            chunks = snapped;
+    }
+    chunks = std::min<long>(chunks, std::max(out_rows, 1));
+    return int((out_rows + chunks - 1) / chunks);
 }
 
 // One kernel launch = T generations over global rows [out_begin, out_end).
@@ -498,8 +525,14 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
                                                     dom.row_origin + std::int64_t(dom.local_rows)));
     g.out_begin = std::int32_t(out_begin);
     g.out_end = std::int32_t(out_end);
+    constexpr unsigned waves_per_block = 4;
+    const void *kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd>);
+    static int resident_blocks = 0; // per kernel instantiation
+    if (resident_blocks == 0)
+        check(ststhip_occupancy(kernel, waves_per_block * wave_size, 0, &resident_blocks), "occupancy query");
     g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW);
-    g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), g.n_strips, SW::G);
+    g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), g.n_strips, SW::G, resident_blocks,
+                                   int(waves_per_block));
     g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
     g.pitch = dom.pitch;
     g.iteration = iteration;
@@ -510,10 +543,9 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     }(std::make_index_sequence<std::size_t(T)>{});
 
     const unsigned waves = g.n_strips * g.n_chunks;
-    const unsigned waves_per_block = 4;
     const unsigned blocks = (waves + waves_per_block - 1) / waves_per_block;
     void *kernel_args[] = {&args};
-    check(ststhip_launch(reinterpret_cast<const void *>(&sweep_kernel<SW>), blocks, 1, 1,
+    check(ststhip_launch(kernel, blocks, 1, 1,
                          waves_per_block * wave_size, 1, 1, kernel_args, 0, stream),
           "sweep launch");
 }

@@ -93,6 +93,11 @@ int ststhip_launch(const void *function, unsigned grid_x, unsigned grid_y, unsig
                    unsigned block_x, unsigned block_y, unsigned block_z, void **args,
                    size_t shared_bytes, ststhip_stream stream);
 
+/* Workgroups of `block_threads` threads of kernel `function` that one CU keeps resident (HIP
+ * occupancy query); the sweep launcher sizes its wave grid in whole residency rounds with it. */
+int ststhip_occupancy(const void *function, unsigned block_threads, size_t shared_bytes,
+                      int *blocks_per_cu);
+
 /* AoS <-> per-field planes by byte geometry (the reference's scatter/gather kernels,
  * StencilStream/cuda/StencilUpdate.hpp:294-321 and :408-438).  Field f of cell i is the
  * `field_size[f]` bytes at aos + i*cell_size + field_offset[f]; plane f holds them densely.

@@ -81,11 +81,33 @@ template <typename F, bool SOA> struct AppAdapter {
     }
 };
 
+// A transition function with an explicit pipeline shape (used to register tuning experiments and
+// hand-picked shapes next to the heuristic default).
+template <typename F, int K, int T, int P, int MINW = 1, bool INTERIOR = true> struct Shaped : public F {
+    using Block = typename F::Block;
+    Shaped() = default;
+    Shaped(F const &f) : F(f) {}
+    static Shaped from_params(Block const &b) { return Shaped(F::from_params(b)); }
+};
+
 struct AppRegistrar {
     AppRegistrar(AppEntry const &entry) { register_app(entry); }
 };
 
 } // namespace ststhip_detail
+
+namespace stencil {
+namespace hip {
+template <typename F, int K, int T, int P, int MINW, bool INTERIOR, bool SOA>
+struct SweepTuning<::ststhip_detail::Shaped<F, K, T, P, MINW, INTERIOR>, SOA> {
+    static constexpr int cells_per_lane = K;
+    static constexpr int max_generations = T;
+    static constexpr int prefetch_rows = P;
+    static constexpr bool interior_variant = INTERIOR;
+    static constexpr int min_waves_per_simd = MINW;
+};
+} // namespace hip
+} // namespace stencil
 
 #define STSTHIP_CONCAT2(a, b) a##b
 #define STSTHIP_CONCAT(a, b) STSTHIP_CONCAT2(a, b)

@@ -480,6 +480,19 @@ int ststhip_launch(const void *function, unsigned grid_x, unsigned grid_y, unsig
     return STSTHIP_OK;
 }
 
+int ststhip_occupancy(const void *function, unsigned block_threads, size_t shared_bytes,
+                      int *blocks_per_cu) {
+    if (!function || !blocks_per_cu || block_threads == 0)
+        return fail(STSTHIP_ERR_INVALID, "ststhip_occupancy: bad argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    int blocks = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, function, int(block_threads),
+                                                         shared_bytes));
+    *blocks_per_cu = blocks > 0 ? blocks : 1;
+    return STSTHIP_OK;
+}
+
 int ststhip_scatter_fields(const void *aos, size_t cell_size, size_t n_cells, int n_fields,
                            const size_t *field_offset, const size_t *field_size,
                            void *const *planes, ststhip_stream stream) {

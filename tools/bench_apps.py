@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Throughput of every BASELINE.json GPU configuration on one MI355X, through the C ABI:
+
+  jacobi   Jacobi5General fp32 16384^2               (configs[1], also bench.py)
+  hotspot  HotSpot 2 x fp32 8192^2, per-field planes  (configs[2]; the reference is fp32)
+  fdtd     FDTD coef resolver 4608^2, 2 sub-iterations (configs[3] grid of max_grid.json)
+  conway   Game of Life 16384^2, 1 byte per cell
+
+Prints one JSON line per app: Gcell-updates/s (sub-iterations not counted), ms per launch, and the
+algorithmic HBM rate 2*sizeof(Cell)*n_sub bytes per cell-update against the 8 TB/s roofline.
+Inputs are synthetic and resident in HBM; planes are used directly (no scatter/gather in the loop)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from stencilstream_amd import capi
+
+
+def hotspot_params(n):
+    # examples/hotspot/hotspot.cpp:281-295 in numpy float32/float64 with the same expression types
+    f32, f64 = np.float32, np.float64
+    t_chip, chip = f32(0.0005), f32(0.016)
+    gh, gw = f32(chip / f32(n)), f32(chip / f32(n))
+    cap = f32(f64(0.5) * f64(1.75e6) * f64(t_chip) * f64(gh) * f64(gw))
+    rx = f32(f64(gw) / (f64(2.0) * 100 * f64(t_chip) * f64(gh)))
+    ry = f32(f64(gh) / (f64(2.0) * 100 * f64(t_chip) * f64(gw)))
+    rz = f32(t_chip / f32(f32(f32(100) * gh) * gw))
+    max_slope = f32(f64(3.0e6) / (f64(0.5) * f64(t_chip) * f64(1.75e6)))
+    step = f32(f64(0.001) / f64(max_slope) / f64(1000.0))
+    return capi.HotspotParams(float(f32(1) / rx), float(f32(1) / ry), float(f32(1) / rz), float(step / cap))
+
+
+def run(app, params, halo, planes_a, planes_b, H, W, gens, stream, reps=3):
+    dom = capi.Domain(H, W, 0, H, W)
+    a = [t.data_ptr() for t in planes_a]
+    b = [t.data_ptr() for t in planes_b]
+    capi.app_run(app, params, halo, dom, a, b, 0, gens, blocking=True, stream=stream.cuda_stream)
+    best, launches = 1e9, 1
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        info = capi.app_run(app, params, halo, dom, a, b, 0, gens, blocking=True, stream=stream.cuda_stream)
+        best = min(best, time.perf_counter() - t0)
+        launches = info.n_launches
+    return best, launches
+
+
+def main():
+    which = sys.argv[1:] or ["jacobi", "hotspot", "hotspot_aos", "fdtd", "fdtd_aos", "conway"]
+    capi.init(0)
+    dev = "cuda"
+    stream = torch.cuda.Stream()
+    out = []
+    for name in which:
+        if name == "jacobi":
+            app, H, W, gens = "jacobi5general", 16384, 16384, 200
+            p = capi.JacobiParams()
+            for i in range(5):
+                p.coef[i] = 0.2
+            halo = np.float32(0).tobytes()
+            pa, pb = [torch.rand(H, W, device=dev)], [torch.empty(H, W, device=dev)]
+        elif name in ("hotspot", "hotspot_aos"):
+            app, H, W, gens = name, 8192, 8192, 200
+            p = hotspot_params(H)
+            halo = np.zeros(2, np.float32).tobytes()
+            if name == "hotspot":
+                temp = torch.full((H, W), 30.0, device=dev)
+                power = torch.zeros(H, W, device=dev)
+                power[H // 4 - 1:3 * H // 4, W // 4 - 1:3 * W // 4] = 0.5
+                pa, pb = [temp, power], [torch.empty_like(temp), torch.empty_like(power)]
+            else:
+                cells = torch.zeros(H, W, 2, device=dev)
+                cells[..., 0] = 30.0
+                pa, pb = [cells], [torch.empty_like(cells)]
+        elif name in ("fdtd", "fdtd_aos"):
+            app, H, W, gens = ("fdtd_coef" if name == "fdtd" else "fdtd_coef_aos"), 4608, 4608, 100
+            p = capi.FdtdParams(dt=8.1e-19, t_0=3e-13, tau=1e-13, omega=7.5e14, cutoff_iteration=10 ** 9,
+                                detect_iteration=0, source_radius_squared=100.0, source_r=H / 2, source_c=W / 2,
+                                source_distance_bound=100.0 - 2 * (H / 2) ** 2, double_center_rc=float(H))
+            halo = np.zeros(8, np.float32).tobytes()
+            if name == "fdtd":
+                pa = [torch.rand(H, W, device=dev) * 1e-3 for _ in range(4)] + [torch.full((H, W), v, device=dev) for v in (1.0, 0.3, 1.0, 0.3)]
+                pb = [torch.empty(H, W, device=dev) for _ in range(8)]
+            else:
+                cells = torch.rand(H, W, 8, device=dev) * 1e-3
+                pa, pb = [cells], [torch.empty_like(cells)]
+        elif name == "conway":
+            app, H, W, gens = "conway", 16384, 16384, 200
+            p = capi.NoParams()
+            halo = b"\0"
+            pa = [(torch.rand(H, W, device=dev) < 0.35).to(torch.uint8)]
+            pb = [torch.empty_like(pa[0])]
+        else:
+            raise SystemExit(f"unknown app {name}")
+        torch.cuda.synchronize()
+        info = capi.app_info(app)
+        best, launches = run(app, p, halo, pa, pb, H, W, gens, stream)
+        bytes_per_update = 2 * info.cell_size * info.n_subiterations
+        gcells = H * W * gens / best / 1e9
+        line = {"app": app, "grid": [H, W], "generations": gens, "Gcell_updates_per_s": round(gcells, 1),
+                "ms_per_launch": round(best / launches * 1e3, 4), "generations_per_launch": gens / launches,
+                "algorithmic_bytes_per_cell_update": bytes_per_update,
+                "algorithmic_GBps": round(gcells * bytes_per_update, 1),
+                "frac_of_8TBps": round(gcells * bytes_per_update / 8000.0, 3)}
+        print(json.dumps(line), flush=True)
+        out.append(line)
+        del pa, pb
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(pattern):
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] if files else []
+
+
 def main():
     tag = sys.argv[1]
     kernel_key = sys.argv[2] if len(sys.argv) > 2 else "sweep_kernel"
@@ -22,7 +27,7 @@ def main():
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
 
-    stats = list(csv.DictReader(open(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0])))
+    stats = list(csv.DictReader(open(newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0])))
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
@@ -34,7 +39,7 @@ def main():
     counters = {}
     resources = {}
     for kind, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        files = glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv"))
+        files = newest(os.path.join(src, kind, "*", "*counter_collection.csv"))
         if not files:
             continue
         vals = collections.defaultdict(list)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sweep the launch-shape knobs of the Jacobi sweep on one GPU and print Gcell-updates/s.
 Knobs are environment variables read by the runtime at every launch:
-  STSTHIP_MAX_GENERATIONS (temporal blocking depth cap), STSTHIP_WAVES_PER_CU, STSTHIP_CHUNK_ROWS."""
+  STSTHIP_MAX_GENERATIONS (temporal blocking depth cap), STSTHIP_TAIL_PERMILLE, STSTHIP_CHUNK_ROWS."""
 import itertools
 import os
 import sys
@@ -32,16 +32,16 @@ def main():
     stream = side.cuda_stream
     torch.cuda.synchronize()
     depths = [t for t in (1, 2, 4, 8) if t <= info.max_generations]
-    for T, wpc in itertools.product(depths, (8, 16, 32, 64, 128)):
+    for T, wpc in itertools.product(depths, (125, 250, 500, 1000, 2000)):
         os.environ["STSTHIP_MAX_GENERATIONS"] = str(T)
-        os.environ["STSTHIP_WAVES_PER_CU"] = str(wpc)
+        os.environ["STSTHIP_TAIL_PERMILLE"] = str(wpc)
         capi.app_run(app, p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens, blocking=True, stream=stream)
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter()
             capi.app_run(app, p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens, blocking=True, stream=stream)
             best = min(best, time.perf_counter() - t0)
-        print(f"{app} {size}^2 T={T} waves/CU={wpc}: {size * size * gens / best / 1e9:8.1f} Gcell/s "
+        print(f"{app} {size}^2 T={T} tail permille={wpc}: {size * size * gens / best / 1e9:8.1f} Gcell/s "
               f"({best / (gens / T) * 1e3:.3f} ms/launch)", flush=True)
 
 
