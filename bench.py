@@ -193,6 +193,20 @@ def main():
                     out["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
                 except Exception:
                     pass
+            # the same kernel with fused multiply-adds (not bit-identical to the reference's cpu backend;
+            # reported for information only, never as `value`)
+            try:
+                capi.app_info(app + "_fma")
+                capi.app_run(app + "_fma", p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens, blocking=True,
+                             stream=stream.cuda_stream)
+                t1 = time.perf_counter()
+                capi.app_run(app + "_fma", p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens, blocking=True,
+                             stream=stream.cuda_stream)
+                dt = time.perf_counter() - t1
+                out["fma_flavour"] = {"value": H * W * gens / dt / 1e9, "unit": "Gcell-updates/s",
+                                      "note": "-ffp-contract=fast build of the same kernel; tolerance parity only"}
+            except capi.StsthipError:
+                pass
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_generations)
         print(json.dumps(out), flush=True)

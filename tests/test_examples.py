@@ -149,10 +149,12 @@ FDTD_EXPERIMENT = {
 
 
 @pytest.mark.gpu
-def test_fdtd_hip_equals_cpu_backend(tmp_path):
-    """examples/fdtd unchanged (coef resolver, snapshots => several update calls with
-    iteration_offset): every CSV the MI355X build writes equals the cpu-backend build's, text for text."""
-    hip_bin, cpu_bin = exe("fdtd_hip"), exe("fdtd_cpu")
+@pytest.mark.parametrize("variant", ["", "_lut", "_render"], ids=["coef", "lut", "render"])
+def test_fdtd_hip_equals_cpu_backend(tmp_path, variant):
+    """examples/fdtd unchanged (coef / LUT / render material resolvers, all three TDV strategy
+    names, snapshots => several update calls with iteration_offset): every CSV the MI355X build writes
+    equals the cpu-backend build's, text for text."""
+    hip_bin, cpu_bin = exe(f"fdtd{variant}_hip"), exe(f"fdtd{variant}_cpu")
     cfg = tmp_path / "experiment.json"
     cfg.write_text(json.dumps(FDTD_EXPERIMENT))
     outs = {}

@@ -284,3 +284,44 @@ def test_strip_domain_single_rank_on_gpu(gpu, oracle):
     got = strip.owned(0, torch.float32).cpu().numpy()
     want = oracle.jacobi("Jacobi5General", coef, grid, 21, halo=0.0, n_threads=8)
     assert np.array_equal(bits(got), bits(want))
+
+
+def test_jacobi_fma_flavour_within_tolerance(gpu, oracle):
+    """The fused-multiply-add build of the headline kernel: not bit-identical by construction, checked
+    against the uncontracted oracle with the tolerance DESIGN.md states (<= 4 ulp per generation on
+    values in [0, 1], non-accumulating because the update is a convex combination)."""
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(77)
+    grid = rng.random((257, 511), dtype=np.float32)
+    coef = [0.2] * 5
+    tf = U.jacobi("Jacobi5General", coef)
+    tf.app = "jacobi5general_fma"
+    for n in (1, 8, 29, 100):
+        got = run_hip(tf, grid, n, halo=np.float32(0.0))
+        want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=0.0, n_threads=8)
+        assert np.abs(got.astype(np.float64) - want).max() <= 4 * np.finfo(np.float32).eps * min(n, 8)
+        assert not np.array_equal(got, want) or n == 0 or True  # may or may not differ; only the bound matters
+
+
+def test_native_comm_single_rank(gpu):
+    """ststhip_comm_* (RCCL through the C ABI) with one rank: create, no-op exchange, destroy."""
+    import ctypes as C
+
+    import torch
+
+    from stencilstream_amd import capi
+
+    lib = capi.load()
+    uid = C.create_string_buffer(capi.COMM_ID_BYTES)
+    capi.check(lib.ststhip_comm_unique_id(uid), "ststhip_comm_unique_id")
+    comm = C.c_void_p()
+    capi.check(lib.ststhip_comm_create(uid, 0, 1, C.byref(comm)), "ststhip_comm_create")
+    a = torch.arange(64, dtype=torch.float32, device=gpu)
+    ptrs = (C.c_void_p * 1)(a.data_ptr())
+    row_bytes = (C.c_size_t * 1)(16)
+    capi.check(lib.ststhip_comm_exchange_rows(comm, 1, ptrs, ptrs, ptrs, ptrs, row_bytes, 2, None),
+               "ststhip_comm_exchange_rows")
+    torch.cuda.synchronize()
+    assert torch.equal(a.cpu(), torch.arange(64, dtype=torch.float32))  # no neighbours: nothing moves
+    capi.check(lib.ststhip_comm_destroy(comm), "ststhip_comm_destroy")
