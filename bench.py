@@ -34,6 +34,8 @@ def parse_args():
     ap.add_argument("--size", type=int, default=16384, help="grid rows (per GPU) and columns")
     ap.add_argument("--generations", type=int, default=200, help="generations per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-strip", action="store_true",
+                    help="one full-grid launch per pass (no row strips on side streams); used for profiling")
     ap.add_argument("--cpu-size", type=int, default=8192)
     ap.add_argument("--cpu-generations", type=int, default=16)
     return ap.parse_args()
@@ -70,6 +72,8 @@ def cpu_baseline(size, generations):
 
 def main():
     args = parse_args()
+    if args.single_strip:
+        os.environ["STSTHIP_VIRTUAL_STRIPS"] = "1"
     import numpy as np
     import torch
 
@@ -126,14 +130,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
-    launches = 0
     for _ in range(args.steps):
-        r = step()
-        launches += r.n_launches if r is not None else 0
-    ev1.record(stream)
+        step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -170,9 +169,20 @@ def main():
             },
         }
         if world == 1:
-            # the dominant (only) kernel: per launch it advances H*W cells by T generations
-            kernel_ms = ev0.elapsed_time(ev1) / max(launches, 1)
-            T = gens * args.steps / max(launches, 1)
+            # The dominant (only) kernel, measured live: full-grid launches (one row strip) of T
+            # generations, HIP events around every launch on the launch stream.
+            saved = os.environ.get("STSTHIP_VIRTUAL_STRIPS")
+            os.environ["STSTHIP_VIRTUAL_STRIPS"] = "1"
+            try:
+                prof = capi.app_run(app, p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens, blocking=True,
+                                    profiling=True, stream=stream.cuda_stream)
+            finally:
+                if saved is None:
+                    del os.environ["STSTHIP_VIRTUAL_STRIPS"]
+                else:
+                    os.environ["STSTHIP_VIRTUAL_STRIPS"] = saved
+            kernel_ms = prof.kernel_time_s * 1e3 / max(prof.n_launches, 1)
+            T = gens / max(prof.n_launches, 1)
             alg_bytes = H * W * BYTES_PER_CELL_UPDATE * T
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
             out["roofline"] = {
@@ -182,10 +192,12 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": "sweep_kernel<Jacobi5General>",
+                "kernel": "sweep_kernel<Sweep<Jacobi<General5>, AoS, T=8, K=4, P=4>>",
                 "kernel_ms": kernel_ms,
+                "launches_timed": int(prof.n_launches),
                 "generations_per_launch": T,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "full-grid launches; `value` additionally overlaps two row strips on two streams",
             }
             traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
             if os.path.exists(traffic_file):

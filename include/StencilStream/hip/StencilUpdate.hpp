@@ -46,34 +46,19 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
     };
 
     StencilUpdate(Params params)
-        : params(params), n_processed_cells(0), walltime(0.0), kernel_runtime(0.0), timed() {}
-
-    StencilUpdate(StencilUpdate const &other)
-        : params(other.params), n_processed_cells(other.n_processed_cells),
-          walltime(other.walltime), kernel_runtime(other.get_kernel_runtime()), timed() {}
-
-    ~StencilUpdate() { drop_events(); }
+        : params(params), n_processed_cells(0), walltime(0.0), kernel_runtime(0.0) {}
 
     Params &get_params() { return params; }
     std::size_t get_n_processed_cells() const { return n_processed_cells; }
     double get_walltime() const { return walltime; }
 
-    // Sum of the sweep kernels' device time in seconds; needs Params::profiling.
-    double get_kernel_runtime() const {
-        double seconds = kernel_runtime;
-        for (auto const &pair : timed) {
-            float ms = 0.0f;
-            ststhip_event_synchronize(pair.second);
-            if (ststhip_event_elapsed_ms(pair.first, pair.second, &ms) == STSTHIP_OK)
-                seconds += double(ms) * 1e-3;
-        }
-        return seconds;
-    }
+    // Sum of the sweep kernels' device time in seconds (HIP events around every launch); needs
+    // Params::profiling, which also makes the call synchronous.
+    double get_kernel_runtime() const { return kernel_runtime; }
 
     GridImpl operator()(GridImpl &source_grid) {
         internal::ensure_runtime(params.device.hip_index());
         ststhip_stream stream = internal::default_stream();
-        fold_events();
 
         auto started = std::chrono::high_resolution_clock::now();
         GridImpl result = simulate(source_grid, stream);
@@ -89,38 +74,51 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
     }
 
   private:
-    // All passes of one call: `remaining` generations in chunks of the compiled blocking depths.
-    template <typename NextTarget>
-    void run_passes(ststhip_domain const &dom, Planes first_source, NextTarget &&next_target,
-                    ststhip_stream stream) {
-        Planes source = first_source;
-        std::uint64_t iteration = params.iteration_offset;
-        std::uint64_t remaining = params.n_iterations;
-        std::vector<TDV> tdv;
-        while (remaining > 0) {
-            const int depth = internal::next_pass_depth<F, split_cell_structure>(remaining);
-            tdv.clear();
-            for (int t = 0; t < depth; t++) // host side, once per generation
-                tdv.push_back(params.transition_function.get_time_dependent_value(iteration + t));
-            Planes target = next_target();
-
-            ststhip_event ev_start = nullptr, ev_stop = nullptr;
-            if (params.profiling) {
-                internal::check(ststhip_event_create(&ev_start), "event create");
-                internal::check(ststhip_event_create(&ev_stop), "event create");
-                ststhip_event_record(ev_start, stream);
+    // One launch, called back by the runtime's pass driver (ststhip_run_passes): evaluates the
+    // time-dependent values of the launch's generations on the host and starts the sweep kernel that
+    // was instantiated for F in this translation unit.
+    static int sweep_trampoline(void *ctx, const ststhip_domain *dom, const void *const *src,
+                                void *const *dst, std::uint64_t out_begin, std::uint64_t out_end,
+                                std::uint64_t iteration, std::uint32_t depth, ststhip_stream stream) {
+        StencilUpdate const *self = static_cast<StencilUpdate const *>(ctx);
+        try {
+            std::vector<TDV> tdv;
+            tdv.reserve(depth);
+            for (std::uint32_t t = 0; t < depth; t++)
+                tdv.push_back(self->params.transition_function.get_time_dependent_value(iteration + t));
+            Planes from, to;
+            for (int f = 0; f < Planes::n_planes; f++) {
+                from.plane[f] = const_cast<void *>(src[f]);
+                to.plane[f] = dst[f];
             }
             internal::dispatch_sweep<F, split_cell_structure>(
-                depth, params.transition_function, params.halo_value, tdv.data(), dom, source,
-                target, 0, dom.global_height, iteration, stream);
-            if (params.profiling) {
-                ststhip_event_record(ev_stop, stream);
-                timed.emplace_back(ev_start, ev_stop);
-            }
-            source = target;
-            iteration += depth;
-            remaining -= depth;
+                int(depth), self->params.transition_function, self->params.halo_value, tdv.data(),
+                *dom, from, to, out_begin, out_end, iteration, stream);
+            return STSTHIP_OK;
+        } catch (internal::runtime_error const &e) {
+            return e.status;
+        } catch (std::exception const &e) {
+            ststhip_set_last_error(e.what());
+            return STSTHIP_ERR_INVALID;
         }
+    }
+
+    // All passes of one call, from `source` planes into `target` planes.
+    void run_passes(ststhip_domain const &dom, Planes const &source, Planes const &target,
+                    ststhip_stream stream) {
+        ststhip_sweep_desc desc = {};
+        desc.n_planes = Planes::n_planes;
+        desc.max_generations = SweepTuning<F, split_cell_structure>::max_generations;
+        desc.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
+        for (int f = 0; f < Planes::n_planes; f++)
+            desc.plane_elem_size[f] = Planes::elem_size(f);
+        ststhip_run_info info = {};
+        internal::check(ststhip_run_passes(&sweep_trampoline, this, &desc, &dom,
+                                           const_cast<const void *const *>(source.plane), target.plane,
+                                           params.iteration_offset, params.n_iterations, 0,
+                                           params.profiling ? 1 : 0, stream, &info),
+                        "ststhip_run_passes");
+        kernel_runtime += info.kernel_time_s;
     }
 
     GridImpl simulate(GridImpl &source_grid, ststhip_stream stream)
@@ -129,21 +127,12 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
         if (params.n_iterations == 0)
             return source_grid;
         ststhip_domain dom = domain_of(source_grid);
-        GridImpl scratch[2] = {source_grid.make_similar(), source_grid.make_similar()};
-        Planes first;
-        first.plane[0] = const_cast<Cell *>(source_grid.device_cells());
-        int slot = 1, last_written = -1;
-        run_passes(
-            dom, first,
-            [&]() {
-                slot ^= 1;
-                last_written = slot;
-                Planes target;
-                target.plane[0] = scratch[slot].device_cells_for_overwrite();
-                return target;
-            },
-            stream);
-        return scratch[last_written];
+        GridImpl result = source_grid.make_similar();
+        Planes from, to;
+        from.plane[0] = const_cast<Cell *>(source_grid.device_cells());
+        to.plane[0] = result.device_cells_for_overwrite();
+        run_passes(dom, from, to, stream);
+        return result;
     }
 
     GridImpl simulate(GridImpl &source_grid, ststhip_stream stream)
@@ -165,19 +154,11 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
         internal::check(ststhip_scatter_fields(source_grid.device_cells(), sizeof(Cell), n_cells, n,
                                                offsets, sizes, sets[0].plane, stream),
                         "scatter");
-        int slot = 0;
-        run_passes(
-            dom, sets[0],
-            [&]() {
-                slot ^= 1;
-                return sets[slot];
-            },
-            stream);
+        run_passes(dom, sets[0], sets[1], stream); // n_iterations == 0 copies the planes
         GridImpl result = source_grid.make_similar();
         internal::check(ststhip_gather_fields(result.device_cells_for_overwrite(), sizeof(Cell),
                                               n_cells, n, offsets, sizes,
-                                              const_cast<const void *const *>(sets[slot].plane),
-                                              stream),
+                                              const_cast<const void *const *>(sets[1].plane), stream),
                         "gather");
         // pool blocks are recycled in stream order, so they can be returned while work is queued
         for (auto &set : sets)
@@ -196,23 +177,10 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
         return dom;
     }
 
-    void fold_events() {
-        kernel_runtime = get_kernel_runtime();
-        drop_events();
-    }
-    void drop_events() {
-        for (auto &pair : timed) {
-            ststhip_event_destroy(pair.first);
-            ststhip_event_destroy(pair.second);
-        }
-        timed.clear();
-    }
-
     Params params;
     std::size_t n_processed_cells;
     double walltime;
     double kernel_runtime;
-    std::vector<std::pair<ststhip_event, ststhip_event>> timed;
 };
 
 } // namespace hip

@@ -52,6 +52,8 @@ typedef void *ststhip_event;  /* a hipEvent_t */
 /* ------------------------------------------------------------- layer 0 */
 int ststhip_abi_version(void);
 const char *ststhip_last_error(void);
+/* Lets code on the caller's side of a callback (ststhip_sweep_fn) report why it failed. */
+void ststhip_set_last_error(const char *message);
 
 /* Select a GPU for the calling process (device < 0: keep the current HIP device) and create the
  * runtime's stream.  Idempotent.  Fails with STSTHIP_ERR_NO_DEVICE when no GPU is visible. */
@@ -173,6 +175,27 @@ int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cel
                     const ststhip_domain *dom, const void *const *src, void *const *dst,
                     uint64_t iteration_offset, uint64_t n_iterations, int blocking,
                     int profiling, ststhip_stream stream, ststhip_run_info *info);
+
+/* The pass driver behind ststhip_app_run and stencil::hip::StencilUpdate: splits n_iterations into
+ * launches of the compiled blocking depths, ping-pongs between `dst` and pooled scratch planes so
+ * that the last pass lands in `dst` (`src` is never written), and -- for tall grids -- advances
+ * several row strips on separate streams coupled only through their boundary bands, so that the
+ * tail of one launch overlaps with the next launches.  `sweep` performs one launch (for C++
+ * transition functions it is instantiated in the user's translation unit). */
+typedef int (*ststhip_sweep_fn)(void *ctx, const ststhip_domain *dom, const void *const *src,
+                                void *const *dst, uint64_t out_row_begin, uint64_t out_row_end,
+                                uint64_t iteration, uint32_t n_generations, ststhip_stream stream);
+typedef struct {
+    uint32_t n_planes;
+    uint32_t max_generations;           /* deepest blocking `sweep` accepts (powers of two up to it) */
+    uint32_t halo_depth_per_generation; /* radius * n_subiterations */
+    uint32_t reserved;
+    uint64_t plane_elem_size[16];
+} ststhip_sweep_desc;
+int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc,
+                       const ststhip_domain *dom, const void *const *src, void *const *dst,
+                       uint64_t iteration_offset, uint64_t n_iterations, int blocking, int profiling,
+                       ststhip_stream stream, ststhip_run_info *info);
 
 /* Parameter blocks of the precompiled transition functions (plain data, host side). */
 typedef struct {

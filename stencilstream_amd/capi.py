@@ -118,6 +118,8 @@ def load():
         )
     lib = C.CDLL(LIB_PATH)
     lib.ststhip_last_error.restype = C.c_char_p
+    lib.ststhip_set_last_error.argtypes = [C.c_char_p]
+    lib.ststhip_set_last_error.restype = None
     vp, sz, u64, u32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32
     pp = C.POINTER(C.c_void_p)
     sigs = {
@@ -156,6 +158,8 @@ def load():
         "ststhip_app_sweep": [C.c_char_p, vp, vp, C.POINTER(Domain), pp, pp, u64, u64, u64, u32, vp],
         "ststhip_app_run": [C.c_char_p, vp, vp, C.POINTER(Domain), pp, pp, u64, u64, C.c_int, C.c_int,
                             vp, C.POINTER(RunInfo)],
+        "ststhip_run_passes": [vp, vp, vp, C.POINTER(Domain), pp, pp, u64, u64, C.c_int, C.c_int, vp,
+                               C.POINTER(RunInfo)],
         "ststhip_comm_unique_id": [C.c_char_p],
         "ststhip_comm_create": [C.c_char_p, C.c_int, C.c_int, pp],
         "ststhip_comm_destroy": [vp],

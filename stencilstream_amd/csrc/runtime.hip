@@ -253,6 +253,7 @@ extern "C" {
 
 int ststhip_abi_version(void) { return STSTHIP_ABI_VERSION; }
 const char *ststhip_last_error(void) { return g_last_error.c_str(); }
+void ststhip_set_last_error(const char *message) { set_error(message); }
 
 int ststhip_init(int device) {
     Runtime &r = rt();
@@ -597,67 +598,165 @@ int ststhip_app_sweep(const char *app, const void *tf_params, const void *halo_c
                     n_generations, resolve(stream));
 }
 
-int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cell,
-                    const ststhip_domain *dom, const void *const *src, void *const *dst,
-                    uint64_t iteration_offset, uint64_t n_iterations, int blocking, int profiling,
-                    ststhip_stream stream, ststhip_run_info *info) {
-    const AppEntry *e = find_app(app);
-    if (!e)
-        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
-    if (!tf_params || !halo_cell || !src || !dst || !dom)
+// ------------------------------------------------------------------ pass driver
+// Side streams for "virtual strips": one launch per pass has a ramp-up and a ragged tail during which
+// part of the chip idles (at 16384^2 a pass is only ~3 residency rounds long).  Splitting the rows
+// into V strips that advance on V streams, coupled only through their G-row boundary bands, lets
+// the tail of one strip's kernel overlap with the next kernels of the other strips.
+static std::vector<hipStream_t> &side_streams() {
+    static std::vector<hipStream_t> streams;
+    return streams;
+}
+
+static std::vector<std::uint32_t> plan_depths(std::uint64_t n_iterations, std::uint32_t max_generations) {
+    std::vector<std::uint32_t> depths;
+    int cap = stencil::hip::internal::env_int("STSTHIP_MAX_GENERATIONS", int(max_generations));
+    std::uint64_t remaining = n_iterations;
+    while (remaining > 0) {
+        std::uint32_t t = max_generations;
+        while (t > 1 && (t > remaining || int(t) > cap))
+            t /= 2;
+        depths.push_back(t);
+        remaining -= t;
+    }
+    return depths;
+}
+
+int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc,
+                       const ststhip_domain *dom, const void *const *src, void *const *dst,
+                       uint64_t iteration_offset, uint64_t n_iterations, int blocking, int profiling,
+                       ststhip_stream stream, ststhip_run_info *info) {
+    if (!sweep || !desc || !dom || !src || !dst)
         return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (desc->n_planes < 1 || desc->n_planes > 16 || desc->max_generations < 1)
+        return fail(STSTHIP_ERR_INVALID, "bad sweep description");
     if (dom->row_origin != 0 || dom->local_rows != dom->global_height)
-        return fail(STSTHIP_ERR_INVALID, "ststhip_app_run works on whole grids (row_origin 0)");
+        return fail(STSTHIP_ERR_INVALID, "the pass driver works on whole grids (row_origin 0)");
     if (int rc = ststhip_init(-1))
         return rc;
     hipStream_t s = resolve(stream);
-    const unsigned n_planes = e->info.n_planes;
+    const unsigned n_planes = desc->n_planes;
     const std::size_t plane_cells = std::size_t(dom->local_rows) * dom->pitch;
+    const std::uint64_t H = dom->global_height;
     auto started = std::chrono::high_resolution_clock::now();
 
-    // passes: greedy powers of two
-    std::vector<std::uint32_t> depths;
-    {
-        int cap = stencil::hip::internal::env_int("STSTHIP_MAX_GENERATIONS", int(e->info.max_generations));
-        std::uint64_t remaining = n_iterations;
-        while (remaining > 0) {
-            std::uint32_t t = e->info.max_generations;
-            while (t > 1 && (t > remaining || int(t) > cap))
-                t /= 2;
-            depths.push_back(t);
-            remaining -= t;
-        }
-    }
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    const std::vector<std::uint32_t> depths = plan_depths(n_iterations, desc->max_generations);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+    std::vector<hipEvent_t> sync_events;
+    std::uint64_t n_launches = 0;
     int rc = STSTHIP_OK;
     void *scratch[16] = {nullptr};
+
+    // how many virtual strips: only worth it for grids with many rows per strip
+    const std::uint64_t g_max = std::uint64_t(desc->max_generations) * desc->halo_depth_per_generation;
+    int strips = stencil::hip::internal::env_int("STSTHIP_VIRTUAL_STRIPS", 0);
+    if (strips <= 0)
+        strips = (H >= 8192 && depths.size() >= 2) ? 2 : 1;
+    if (profiling || H < std::uint64_t(strips) * 8 * std::max<std::uint64_t>(g_max, 1))
+        strips = 1;
+    strips = std::min(strips, 8);
+
     if (depths.empty()) {
         for (unsigned p = 0; p < n_planes && rc == STSTHIP_OK; p++)
-            rc = ststhip_memcpy_d2d(dst[p], src[p], plane_cells * e->info.plane_elem_size[p], s);
+            rc = ststhip_memcpy_d2d(dst[p], src[p], plane_cells * desc->plane_elem_size[p], s);
     } else {
         if (depths.size() > 1)
             for (unsigned p = 0; p < n_planes && rc == STSTHIP_OK; p++)
-                rc = ststhip_malloc(&scratch[p], plane_cells * e->info.plane_elem_size[p]);
+                rc = ststhip_malloc(&scratch[p], plane_cells * desc->plane_elem_size[p]);
+
+        auto new_event = [&]() {
+            hipEvent_t e = nullptr;
+            hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            sync_events.push_back(e);
+            return e;
+        };
+        // streams of the strips: strip 0 runs on the caller's stream
+        std::vector<hipStream_t> lane(strips, s);
+        if (strips > 1 && rc == STSTHIP_OK) {
+            auto &pool = side_streams();
+            while (int(pool.size()) < strips - 1) {
+                hipStream_t extra;
+                if (hipStreamCreateWithFlags(&extra, hipStreamNonBlocking) != hipSuccess) {
+                    strips = 1;
+                    break;
+                }
+                pool.push_back(extra);
+            }
+            if (strips > 1) {
+                hipEvent_t begin = new_event();
+                hipEventRecord(begin, s);
+                for (int v = 1; v < strips; v++) {
+                    lane[v] = pool[v - 1];
+                    hipStreamWaitEvent(lane[v], begin, 0);
+                }
+            } else {
+                lane.assign(1, s);
+            }
+        }
+        std::vector<std::uint64_t> bound(strips + 1);
+        for (int v = 0; v <= strips; v++)
+            bound[v] = H * std::uint64_t(v) / std::uint64_t(strips);
+        if (strips == 2) // unequal strips drift out of phase, so one strip's tail meets the other's bulk
+            bound[1] = H * std::uint64_t(stencil::hip::internal::env_int("STSTHIP_STRIP_SKEW_PERMILLE", 400)) / 1000;
+        std::vector<hipEvent_t> bands_done(strips, nullptr); // per strip: bands of the previous pass
+
         // the last pass must land in dst; the input is never written
         const void *const *from = src;
         std::uint64_t iteration = iteration_offset;
         for (std::size_t pass = 0; pass < depths.size() && rc == STSTHIP_OK; pass++) {
             const bool into_dst = ((depths.size() - 1 - pass) % 2) == 0;
             void *const *to = into_dst ? dst : scratch;
-            hipEvent_t a = nullptr, b = nullptr;
+            const std::uint64_t g = std::uint64_t(depths[pass]) * desc->halo_depth_per_generation;
+            hipEvent_t t0 = nullptr, t1 = nullptr;
             if (profiling) {
-                hipEventCreate(&a);
-                hipEventCreate(&b);
-                hipEventRecord(a, s);
+                hipEventCreate(&t0);
+                hipEventCreate(&t1);
+                hipEventRecord(t0, s);
             }
-            rc = ststhip_app_sweep(app, tf_params, halo_cell, dom, from, to, 0, dom->global_height,
-                                   iteration, depths[pass], s);
+            std::vector<hipEvent_t> bands_now(strips, nullptr);
+            for (int v = 0; v < strips && rc == STSTHIP_OK; v++) {
+                const std::uint64_t a = bound[v], b = bound[v + 1];
+                if (strips == 1) {
+                    rc = sweep(ctx, dom, from, to, a, b, iteration, depths[pass], lane[v]);
+                    n_launches++;
+                    continue;
+                }
+                // bands read the neighbours' bands of the previous pass (and will overwrite rows
+                // the neighbours' previous bands read): wait for them
+                if (v > 0 && bands_done[v - 1])
+                    hipStreamWaitEvent(lane[v], bands_done[v - 1], 0);
+                if (v + 1 < strips && bands_done[v + 1])
+                    hipStreamWaitEvent(lane[v], bands_done[v + 1], 0);
+                const std::uint64_t top_end = (v > 0) ? std::min(a + g, b) : a;
+                const std::uint64_t bot_begin = (v + 1 < strips) ? std::max(b - std::min(g, b - a), top_end) : b;
+                if (top_end > a) {
+                    rc = sweep(ctx, dom, from, to, a, top_end, iteration, depths[pass], lane[v]);
+                    n_launches++;
+                }
+                if (rc == STSTHIP_OK && bot_begin < b) {
+                    rc = sweep(ctx, dom, from, to, bot_begin, b, iteration, depths[pass], lane[v]);
+                    n_launches++;
+                }
+                bands_now[v] = new_event();
+                hipEventRecord(bands_now[v], lane[v]);
+                if (rc == STSTHIP_OK && top_end < bot_begin) {
+                    rc = sweep(ctx, dom, from, to, top_end, bot_begin, iteration, depths[pass], lane[v]);
+                    n_launches++;
+                }
+            }
+            bands_done.swap(bands_now);
             if (profiling) {
-                hipEventRecord(b, s);
-                events.emplace_back(a, b);
+                hipEventRecord(t1, s);
+                timed.emplace_back(t0, t1);
             }
             from = const_cast<const void *const *>(to);
             iteration += depths[pass];
+        }
+        // join: the caller's stream continues after every strip has finished
+        for (int v = 1; v < strips; v++) {
+            hipEvent_t done = new_event();
+            hipEventRecord(done, lane[v]);
+            hipStreamWaitEvent(s, done, 0);
         }
     }
     if (rc == STSTHIP_OK && (blocking || profiling)) {
@@ -667,23 +766,66 @@ int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cel
     }
     for (unsigned p = 0; p < n_planes; p++)
         if (scratch[p])
-            ststhip_free(scratch[p]);
+            ststhip_free(scratch[p]); // recycled in stream order of the caller's stream (joined above)
     double kernel_s = 0.0;
-    for (auto &ev : events) {
+    for (auto &ev : timed) {
         float ms = 0.0f;
         if (rc == STSTHIP_OK && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess)
             kernel_s += double(ms) * 1e-3;
         hipEventDestroy(ev.first);
         hipEventDestroy(ev.second);
     }
+    for (hipEvent_t e : sync_events)
+        hipEventDestroy(e);
     if (info) {
         std::chrono::duration<double> elapsed = std::chrono::high_resolution_clock::now() - started;
         info->walltime_s = elapsed.count();
         info->kernel_time_s = kernel_s;
-        info->n_launches = depths.size();
+        info->n_launches = n_launches;
         info->n_processed_cells = n_iterations * dom->global_height * dom->global_width;
     }
     return rc;
+}
+
+namespace {
+struct AppCall {
+    const AppEntry *entry;
+    const void *tf_params;
+    const void *halo_cell;
+};
+int app_sweep_trampoline(void *ctx, const ststhip_domain *dom, const void *const *src, void *const *dst,
+                         uint64_t out_begin, uint64_t out_end, uint64_t iteration, uint32_t n_generations,
+                         ststhip_stream stream) {
+    const AppCall *call = static_cast<const AppCall *>(ctx);
+    return call->entry->sweep(call->tf_params, call->halo_cell, dom, src, dst, out_begin, out_end, iteration,
+                              n_generations, stream);
+}
+} // namespace
+
+int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cell,
+                    const ststhip_domain *dom, const void *const *src, void *const *dst,
+                    uint64_t iteration_offset, uint64_t n_iterations, int blocking, int profiling,
+                    ststhip_stream stream, ststhip_run_info *info) {
+    const AppEntry *e = find_app(app);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    if (!tf_params || !halo_cell || !src || !dst || !dom)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (dom->pitch < dom->global_width)
+        return fail(STSTHIP_ERR_INVALID, "pitch smaller than the grid width");
+    for (unsigned p = 0; p < e->info.n_planes; p++)
+        if (!src[p] || !dst[p] || src[p] == dst[p])
+            return fail(STSTHIP_ERR_INVALID, "source and target planes must be distinct non-null buffers");
+    ststhip_sweep_desc desc;
+    std::memset(&desc, 0, sizeof desc);
+    desc.n_planes = e->info.n_planes;
+    desc.max_generations = e->info.max_generations;
+    desc.halo_depth_per_generation = e->info.halo_depth_per_generation;
+    for (unsigned p = 0; p < e->info.n_planes; p++)
+        desc.plane_elem_size[p] = e->info.plane_elem_size[p];
+    AppCall call{e, tf_params, halo_cell};
+    return ststhip_run_passes(app_sweep_trampoline, &call, &desc, dom, src, dst, iteration_offset,
+                              n_iterations, blocking, profiling, stream, info);
 }
 
 // ------------------------------------------------------------------ multi-GPU

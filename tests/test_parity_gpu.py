@@ -325,3 +325,73 @@ def test_native_comm_single_rank(gpu):
     torch.cuda.synchronize()
     assert torch.equal(a.cpu(), torch.arange(64, dtype=torch.float32))  # no neighbours: nothing moves
     capi.check(lib.ststhip_comm_destroy(comm), "ststhip_comm_destroy")
+
+
+def test_baseline_size_properties(gpu, oracle):
+    """BASELINE config 1 size (Jacobi5General 16384^2): (1) temporal blocking is invisible -- the
+    8-generations-per-launch path equals the 1-generation-per-launch path bit for bit; (2) windows of the
+    result (grid corners, edges, interior, the rim of the initial square) equal the oracle run on the
+    window plus a margin of n cells (cells further than n from the window border cannot be influenced
+    by what lies outside it)."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    N, n = 16384, 16
+    p = capi.JacobiParams()
+    coef = [0.2, 0.21, 0.19, 0.22, 0.18]
+    for i, c in enumerate(coef):
+        p.coef[i] = c
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    src = torch.rand(N, N, device=gpu, generator=gen)
+    src[N // 4:3 * N // 4, N // 4:3 * N // 4] += 1.0
+    deep, flat = torch.empty_like(src), torch.empty_like(src)
+    dom = capi.Domain(N, N, 0, N, N)
+    halo = np.float32(0.125).tobytes()
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    capi.app_run("jacobi5general", p, halo, dom, [src.data_ptr()], [deep.data_ptr()], 0, n, blocking=True,
+                 stream=s.cuda_stream)
+    # reference run: one generation per launch, one strip (the default run above used 8 generations per
+    # launch and two row strips on two streams)
+    os.environ["STSTHIP_MAX_GENERATIONS"] = "1"
+    os.environ["STSTHIP_VIRTUAL_STRIPS"] = "1"
+    try:
+        info = capi.app_run("jacobi5general", p, halo, dom, [src.data_ptr()], [flat.data_ptr()], 0, n,
+                            blocking=True, stream=s.cuda_stream)
+    finally:
+        del os.environ["STSTHIP_MAX_GENERATIONS"]
+        del os.environ["STSTHIP_VIRTUAL_STRIPS"]
+    assert info.n_launches == n
+    assert torch.equal(deep, flat)
+
+    m, w = n, 96
+    for r0, c0 in ((0, 0), (0, N - w), (N - w, 0), (N - w, N - w), (N // 2, N // 2), (N // 4 - 40, N // 4 - 40),
+                   (5000, 0), (0, 9000), (N - w, 12345), (3 * N // 4 - 50, 7000)):
+        ra, rb = max(0, r0 - m), min(N, r0 + w + m)
+        ca, cb = max(0, c0 - m), min(N, c0 + w + m)
+        window = src[ra:rb, ca:cb].cpu().numpy()
+        # outside the window the oracle sees the halo value; at true grid edges that is exact
+        ref = oracle.jacobi("Jacobi5General", coef, window, n, halo=0.125)
+        got = deep[r0:r0 + w, c0:c0 + w].cpu().numpy()
+        want = ref[r0 - ra:r0 - ra + w, c0 - ca:c0 - ca + w]
+        assert np.array_equal(bits(got), bits(want)), (r0, c0)
+
+
+@pytest.mark.parametrize("strips,skew", [(2, 400), (2, 900), (3, 500), (5, 500)])
+def test_virtual_strips_small_grid(gpu, oracle, monkeypatch, strips, skew):
+    """The pass driver's row strips on separate streams (normally only used for tall grids), forced on
+    a small ragged grid: results must not depend on the strip layout."""
+    from stencilstream_amd import update as U
+
+    monkeypatch.setenv("STSTHIP_VIRTUAL_STRIPS", str(strips))
+    monkeypatch.setenv("STSTHIP_STRIP_SKEW_PERMILLE", str(skew))
+    rng = np.random.default_rng(strips * 10 + skew)
+    grid = rng.random((701, 333), dtype=np.float32)
+    coef = [0.2, 0.21, 0.19, 0.22, 0.18]
+    for n in (8, 21, 64):
+        got = run_hip(U.jacobi("Jacobi5General", coef), grid, n, halo=np.float32(0.3))
+        want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=0.3, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"n={n}"
+    life = (rng.random((640, 300)) < 0.4).astype(np.uint8)
+    assert np.array_equal(run_hip(U.conway(), life, 40), oracle.conway(life, 40, n_threads=8))

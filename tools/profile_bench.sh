@@ -7,7 +7,7 @@ REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --single-strip $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$REPO/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$REPO/bench.py" $ARGS > "$OUT/write.log" 2>&1
