@@ -211,30 +211,32 @@ template <typename F, bool SOA> struct SweepTuning {
     static constexpr int R = int(F::stencil_radius);
     static constexpr int NS = int(F::n_subiterations);
     static constexpr int W = internal::cell_words<typename F::Cell, SOA>();
+    // Measured on MI355X (profiles/r01_tune_shapes_apps.txt): the kernel is bound by VALU issue and
+    // occupancy, not by HBM, so the register window T*NS*2R*K*W decides.  One-word cells want K = 4
+    // (fewest DPP moves and halo columns per cell); fatter cells want the narrowest lane that still
+    // covers the radius: K = 2 for two-word AoS cells, K = 1 otherwise.
     static constexpr int pick_k() {
-        int k = 4;
-        while (k > 1 && k / 2 >= R && 2 * R * k * W * NS > 64)
-            k /= 2;
+        int k = (W == 1) ? 4 : ((W == 2 && !SOA) ? 2 : 1);
         return std::max(k, internal::ceil_pow2(R));
     }
+    // deepest power of two up to 8 generations whose window stays within 128 words per lane
     static constexpr int pick_t(int k) {
         int t = 8;
-        while (t > 1 && (t * NS * 2 * R * k * W > 96 || 64 * k <= 2 * internal::round_up(R * t * NS, k)))
+        while (t > 1 && (t * NS * 2 * R * k * W > 128 || 64 * k <= 2 * internal::round_up(R * t * NS, k)))
             t /= 2;
         return t;
     }
-    static constexpr int pick_p(int k) {
+    static constexpr int pick_p() {
         int p = 2 * R;
-        if (k * W <= 8)
-            while (p < 4)
-                p += 2 * R;
+        while (p < 4)
+            p += 2 * R;
         return p;
     }
 
   public:
     static constexpr int cells_per_lane = pick_k();
     static constexpr int max_generations = pick_t(cells_per_lane);
-    static constexpr int prefetch_rows = pick_p(cells_per_lane);
+    static constexpr int prefetch_rows = pick_p();
     static constexpr bool interior_variant = (W * NS <= 16);
     static constexpr int min_waves_per_simd = 1;
 };

@@ -52,6 +52,8 @@ def run(app, params, halo, planes_a, planes_b, H, W, gens, stream, reps=3):
 
 def main():
     which = sys.argv[1:] or ["jacobi", "hotspot", "hotspot_aos", "fdtd", "fdtd_aos", "conway"]
+    if which == ["experiments"]:
+        which = ["hotspot", "fdtd", "fdtd_aos", "conway"] + [a for a in capi.list_apps() if a.startswith(("x_hs_", "x_fd_", "x_cw_"))]
     capi.init(0)
     dev = "cuda"
     stream = torch.cuda.Stream()
@@ -95,6 +97,33 @@ def main():
             halo = b"\0"
             pa = [(torch.rand(H, W, device=dev) < 0.35).to(torch.uint8)]
             pb = [torch.empty_like(pa[0])]
+        elif name.startswith(("x_hs_", "x_fd_", "x_cw_")):
+            # experiments: buffers are built from the registry's own description of the app, so a
+            # name can never be paired with the wrong layout
+            app = name
+            meta = capi.app_info(app)
+            if name.startswith("x_hs_"):
+                H, W, gens, p, fill = 8192, 8192, 192, hotspot_params(8192), [30.0, 0.25]
+            elif name.startswith("x_fd_"):
+                H, W, gens, fill = 4608, 4608, 96, [1e-4, 2e-4, 3e-4, 0.0, 1.0, 0.3, 1.0, 0.3]
+                p = capi.FdtdParams(dt=8.1e-19, t_0=3e-13, tau=1e-13, omega=7.5e14, cutoff_iteration=10 ** 9,
+                                    detect_iteration=0, source_radius_squared=100.0, source_r=H / 2, source_c=W / 2,
+                                    source_distance_bound=100.0 - 2 * (H / 2) ** 2, double_center_rc=float(H))
+            else:
+                H, W, gens, p, fill = 16384, 16384, 192, capi.NoParams(), None
+            halo = bytes(meta.cell_size)
+            if fill is None:
+                pa = [(torch.rand(H, W, device=dev) < 0.35).to(torch.uint8)]
+            elif meta.n_planes == 1:
+                cells = torch.empty(H, W, len(fill), device=dev)
+                for i, v in enumerate(fill):
+                    cells[..., i] = v
+                assert cells.element_size() * len(fill) == meta.cell_size
+                pa = [cells]
+            else:
+                assert meta.n_planes == len(fill) and all(meta.plane_elem_size[i] == 4 for i in range(len(fill)))
+                pa = [torch.full((H, W), v, device=dev) for v in fill]
+            pb = [torch.empty_like(t) for t in pa]
         else:
             raise SystemExit(f"unknown app {name}")
         torch.cuda.synchronize()
