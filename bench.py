@@ -34,6 +34,8 @@ def parse_args():
     ap.add_argument("--size", type=int, default=16384, help="grid rows (per GPU) and columns")
     ap.add_argument("--generations", type=int, default=200, help="generations per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-host-exchange", action="store_true",
+                    help="debugging: all ranks on cuda:0, gloo process group, ghost rows through host memory")
     ap.add_argument("--single-strip", action="store_true",
                     help="one full-grid launch per pass (no row strips on side streams); used for profiling")
     ap.add_argument("--cpu-size", type=int, default=8192)
@@ -85,6 +87,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.debug_host_exchange:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     capi.init(local_rank)
@@ -115,9 +119,13 @@ def main():
 
         from stencilstream_amd.dist import StripDomain
 
-        dist.init_process_group("nccl", device_id=device)
+        if args.debug_host_exchange:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         total_rows = H * world
-        strip = StripDomain(app, p, halo, total_rows, W, rank, world, device, np.dtype("<f4"))
+        strip = StripDomain(app, p, halo, total_rows, W, rank, world, device, np.dtype("<f4"),
+                            exchange_via_host=args.debug_host_exchange)
         strip.load_owned(init_grid_device(torch, H, W, rank * H, total_rows, device))
 
         def step():
@@ -141,7 +149,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if args.debug_host_exchange else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

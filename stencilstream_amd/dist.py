@@ -65,7 +65,7 @@ class StripDomain:
     """The rows of one rank plus ghost rows, double buffered."""
 
     def __init__(self, app, tf_params, halo_bytes, total_rows, width, rank, world, device, cell_dtype=None,
-                 sweep=None, group=None, min_rows_check=True):
+                 sweep=None, group=None, min_rows_check=True, exchange_via_host=False):
         self.sweep = sweep if sweep is not None else HipSweep(app, tf_params, halo_bytes)
         self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
         self.total_rows, self.width = int(total_rows), int(width)
@@ -77,6 +77,9 @@ class StripDomain:
         self.row_origin = self.row_begin - self.g_max
         self.local_rows = (self.row_end - self.row_begin) + 2 * self.g_max
         self.on_gpu = self.device.type == "cuda"
+        # debugging aid: ghost rows travel through host memory, so that the multi-process GPU path can
+        # run where the process group cannot move device memory (gloo; several ranks on one GPU)
+        self.exchange_via_host = bool(exchange_via_host)
         self.planes = [
             [torch.zeros((self.local_rows, self.width * es), dtype=torch.uint8, device=self.device)
              for es in self.sweep.plane_elem_size]
@@ -114,17 +117,30 @@ class StripDomain:
         if self.world == 1 or g == 0:
             return
         o = self._owned_slice()
-        ops = []
+        ops, landed = [], []
         up, down = self.rank - 1, self.rank + 1
+
+        def outgoing(rows):
+            return rows.cpu() if self.exchange_via_host else rows
+
+        def incoming(rows):
+            if not self.exchange_via_host:
+                return rows
+            staged = torch.empty(rows.shape, dtype=rows.dtype)
+            landed.append((rows, staged))
+            return staged
+
         for p in planes:
             if up >= 0:
-                ops.append(dist.P2POp(dist.isend, p[o.start:o.start + g], self._peer(up), self.group))
-                ops.append(dist.P2POp(dist.irecv, p[o.start - g:o.start], self._peer(up), self.group))
+                ops.append(dist.P2POp(dist.isend, outgoing(p[o.start:o.start + g]), self._peer(up), self.group))
+                ops.append(dist.P2POp(dist.irecv, incoming(p[o.start - g:o.start]), self._peer(up), self.group))
             if down < self.world:
-                ops.append(dist.P2POp(dist.isend, p[o.stop - g:o.stop], self._peer(down), self.group))
-                ops.append(dist.P2POp(dist.irecv, p[o.stop:o.stop + g], self._peer(down), self.group))
+                ops.append(dist.P2POp(dist.isend, outgoing(p[o.stop - g:o.stop]), self._peer(down), self.group))
+                ops.append(dist.P2POp(dist.irecv, incoming(p[o.stop:o.stop + g]), self._peer(down), self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        for rows, staged in landed:
+            rows.copy_(staged, non_blocking=False)
 
     def _peer(self, strip_rank):
         return strip_rank if self.group is None else dist.get_global_rank(self.group, strip_rank)

@@ -395,3 +395,54 @@ def test_virtual_strips_small_grid(gpu, oracle, monkeypatch, strips, skew):
         assert np.array_equal(bits(got), bits(want)), f"n={n}"
     life = (rng.random((640, 300)) < 0.4).astype(np.uint8)
     assert np.array_equal(run_hip(U.conway(), life, 40), oracle.conway(life, 40, n_threads=8))
+
+
+def _two_rank_worker(rank, world, port, result_dir):
+    """One of two processes that share cuda:0: real HIP sweeps, real streams and events, ghost rows
+    through host memory over gloo (RCCL cannot put two ranks on one GPU)."""
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stencilstream_amd import capi
+    from stencilstream_amd.dist import StripDomain
+
+    torch.cuda.set_device(0)
+    capi.init(0)
+    H, W = 700, 900
+    grid = np.random.default_rng(99).random((H, W), dtype=np.float32)
+    p = capi.JacobiParams()
+    for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
+        p.coef[i] = c
+    strip = StripDomain("jacobi5general", p, np.float32(0.5).tobytes(), H, W, rank, world, "cuda:0",
+                        exchange_via_host=True)
+    strip.load_owned(torch.from_numpy(grid[strip.row_begin:strip.row_end].copy()).cuda())
+    strip.advance(0, 21)
+    strip.advance(21, 8)
+    np.save(os.path.join(result_dir, f"rank{rank}.npy"), strip.owned(0, torch.float32).cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu(gpu, oracle, tmp_path):
+    """The multi-GPU driver end to end with two processes (boundary-first ordering, second stream,
+    ragged depths 8+8+4+1 and a resume), both on cuda:0."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.get_context("spawn")
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    grid = np.random.default_rng(99).random((700, 900), dtype=np.float32)
+    want = oracle.jacobi("Jacobi5General", [0.2, 0.21, 0.19, 0.22, 0.18], grid, 29, halo=0.5, n_threads=8)
+    got = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(2)], axis=0)
+    assert np.array_equal(bits(got), bits(want))
