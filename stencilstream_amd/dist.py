@@ -147,43 +147,67 @@ class StripDomain:
 
     # ---- time stepping -------------------------------------------------------------------
     def advance(self, iteration_offset, n_generations):
-        """Advance the whole (distributed) grid by n_generations generations."""
+        """Advance the whole (distributed) grid by n_generations generations.
+
+        Per pass, on two streams:
+            comm stream   : wait(interior of pass p-1) -> boundary bands of pass p -> exchange for pass p+1
+            compute stream: wait(bands of pass p-1)    -> interior of pass p
+        Bands and interior of one pass both read the complete result of the previous pass and write
+        disjoint rows, so they run concurrently; the exchange only moves rows the bands produced.
+        """
         depths = pass_depths(n_generations, self.sweep.max_generations)
         iteration = int(iteration_offset)
         a, b = self.row_begin, self.row_end
         cs, ms = self.compute_stream, self.comm_stream
+        gpu = self.on_gpu
 
-        def exchange_for(planes, depth):
-            g = depth * self.sweep.halo_per_generation
-            if self.on_gpu:
-                with torch.cuda.stream(ms):
-                    self._exchange(planes, g)
-            else:
-                self._exchange(planes, g)
+        def on_comm():
+            return torch.cuda.stream(ms) if gpu else _NullContext()
 
-        if depths:
-            if self.on_gpu:
-                ms.wait_stream(cs)
-            exchange_for(self.planes[self.current], depths[0])
+        if not depths:
+            return None
+        if gpu:
+            ms.wait_stream(cs)  # everything queued so far (previous advance, load_owned)
+        with on_comm():
+            self._exchange(self.planes[self.current], depths[0] * self.sweep.halo_per_generation)
+        interior_done = bands_done = None
         for i, depth in enumerate(depths):
             g = depth * self.sweep.halo_per_generation
             src, dst = self.planes[self.current], self.planes[self.current ^ 1]
-            top_end, bot_begin = min(a + g, b), max(b - g, min(a + g, b))
-            if self.on_gpu:
-                cs.wait_stream(ms)  # ghosts of this pass have landed
-            # boundary bands first: the next exchange only needs these rows
-            self.sweep(src, dst, self.dom, a, top_end, iteration, depth, cs)
-            self.n_launches += 1
-            if bot_begin < b:
-                self.sweep(src, dst, self.dom, bot_begin, b, iteration, depth, cs)
-                self.n_launches += 1
-            if i + 1 < len(depths):
-                if self.on_gpu:
-                    ms.wait_stream(cs)
-                exchange_for(dst, depths[i + 1])  # overlaps with the interior sweep below
+            # a band is only needed where there is a neighbour that waits for it
+            top_end = min(a + g, b) if self.rank > 0 else a
+            bot_begin = max(b - g, top_end) if self.rank + 1 < self.world else b
+            # boundary bands, then the exchange that only needs them
+            with on_comm():
+                if gpu and interior_done is not None:
+                    ms.wait_event(interior_done)
+                if a < top_end:
+                    self.sweep(src, dst, self.dom, a, top_end, iteration, depth, ms)
+                    self.n_launches += 1
+                if bot_begin < b:
+                    self.sweep(src, dst, self.dom, bot_begin, b, iteration, depth, ms)
+                    self.n_launches += 1
+                new_bands_done = ms.record_event() if gpu else None
+                if i + 1 < len(depths):
+                    self._exchange(dst, depths[i + 1] * self.sweep.halo_per_generation)
+            # interior, concurrently
+            if gpu and bands_done is not None:
+                cs.wait_event(bands_done)
             if top_end < bot_begin:
                 self.sweep(src, dst, self.dom, top_end, bot_begin, iteration, depth, cs)
                 self.n_launches += 1
+            interior_done = cs.record_event() if gpu else None
+            bands_done = new_bands_done
             self.current ^= 1
             iteration += depth
+        if gpu:
+            cs.wait_stream(ms)  # the compute stream is the one callers synchronise with
         return None
+
+
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

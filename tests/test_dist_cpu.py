@@ -78,9 +78,11 @@ def worker(rank, world, port, kind, H, W, gens, seed, result_dir):
         done += chunk
     mine = strip.owned(0, torch.float32 if kind == "jacobi" else torch.uint8).numpy()
     np.save(os.path.join(result_dir, f"rank{rank}.npy"), mine)
-    # boundary bands must be swept before the interior in every pass
+    # boundary bands must be swept before the interior in every pass: the first launch is a band
+    # (at most one halo depth of rows) next to a neighbour
     first = sweep.calls[0]
-    assert first[0] == a, "first launch of a pass must be the top boundary band"
+    assert first[1] - first[0] <= sweep.max_generations * sweep.halo_per_generation
+    assert (first[0] == a and rank > 0) or (first[1] == b and rank + 1 < world)
     dist.barrier()
     dist.destroy_process_group()
 
