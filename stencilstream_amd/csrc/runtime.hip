@@ -53,6 +53,12 @@ static Runtime &rt() {
     return r;
 }
 
+// side streams of the pass driver (row strips advancing concurrently), created on demand
+static std::vector<hipStream_t> &side_streams() {
+    static std::vector<hipStream_t> streams;
+    return streams;
+}
+
 static std::vector<AppEntry> &apps() {
     static std::vector<AppEntry> registry;
     return registry;
@@ -284,6 +290,11 @@ int ststhip_shutdown(void) {
     if (!r.up)
         return STSTHIP_OK;
     hipStreamSynchronize(r.stream);
+    for (hipStream_t extra : side_streams()) {
+        hipStreamSynchronize(extra);
+        hipStreamDestroy(extra);
+    }
+    side_streams().clear();
     for (auto &kv : r.free_blocks)
         hipFree(kv.second);
     r.free_blocks.clear();
@@ -603,11 +614,6 @@ int ststhip_app_sweep(const char *app, const void *tf_params, const void *halo_c
 // part of the chip idles (at 16384^2 a pass is only ~3 residency rounds long).  Splitting the rows
 // into V strips that advance on V streams, coupled only through their G-row boundary bands, lets
 // the tail of one strip's kernel overlap with the next kernels of the other strips.
-static std::vector<hipStream_t> &side_streams() {
-    static std::vector<hipStream_t> streams;
-    return streams;
-}
-
 static std::vector<std::uint32_t> plan_depths(std::uint64_t n_iterations, std::uint32_t max_generations) {
     std::vector<std::uint32_t> depths;
     int cap = stencil::hip::internal::env_int("STSTHIP_MAX_GENERATIONS", int(max_generations));

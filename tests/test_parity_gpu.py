@@ -446,3 +446,46 @@ def test_two_ranks_on_one_gpu(gpu, oracle, tmp_path):
     want = oracle.jacobi("Jacobi5General", [0.2, 0.21, 0.19, 0.22, 0.18], grid, 29, halo=0.5, n_threads=8)
     got = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(2)], axis=0)
     assert np.array_equal(bits(got), bits(want))
+
+
+def test_empty_and_degenerate_grids(gpu, oracle):
+    """Edge cases of the boundary: zero rows / zero columns, zero generations, one cell."""
+    import torch
+
+    from stencilstream_amd import capi, update as U
+
+    p = capi.JacobiParams()
+    halo = np.float32(0).tobytes()
+    a = torch.zeros(16, device=gpu)
+    b = torch.ones(16, device=gpu)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for H, W in ((0, 0), (0, 4), (4, 0)):
+        info = capi.app_run("jacobi5general", p, halo, capi.Domain(H, W, 0, H, max(W, 1)), [a.data_ptr()],
+                            [b.data_ptr()], 0, 5, blocking=True, stream=s.cuda_stream)
+        assert info.n_processed_cells == 0
+        assert torch.equal(b.cpu(), torch.ones(16))  # nothing written
+    # zero generations copy the source
+    src = torch.arange(12, dtype=torch.float32, device=gpu)
+    dst = torch.zeros(12, device=gpu)
+    torch.cuda.synchronize()
+    capi.app_run("jacobi5general", p, halo, capi.Domain(3, 4, 0, 3, 4), [src.data_ptr()], [dst.data_ptr()], 0, 0,
+                 blocking=True, stream=s.cuda_stream)
+    assert torch.equal(dst.cpu(), torch.arange(12, dtype=torch.float32))
+    # a pitch larger than the width: the padding columns are neither read as cells nor written
+    H, W, pitch = 37, 50, 64
+    rng = np.random.default_rng(3)
+    grid = rng.random((H, W), dtype=np.float32)
+    padded = np.full((H, pitch), np.nan, dtype=np.float32)
+    padded[:, :W] = grid
+    psrc = torch.from_numpy(padded).to(gpu)
+    pdst = torch.full((H, pitch), -7.0, device=gpu)
+    for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
+        p.coef[i] = c
+    torch.cuda.synchronize()
+    capi.app_run("jacobi5general", p, halo, capi.Domain(H, W, 0, H, pitch), [psrc.data_ptr()], [pdst.data_ptr()],
+                 0, 9, blocking=True, stream=s.cuda_stream)
+    out = pdst.cpu().numpy()
+    want = oracle.jacobi("Jacobi5General", [0.2, 0.21, 0.19, 0.22, 0.18], grid, 9, halo=0.0)
+    assert np.array_equal(bits(out[:, :W]), bits(want))
+    assert (out[:, W:] == -7.0).all()
