@@ -110,6 +110,10 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
         desc.n_planes = Planes::n_planes;
         desc.max_generations = SweepTuning<F, split_cell_structure>::max_generations;
         desc.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
+        using Tuning = SweepTuning<F, split_cell_structure>;
+        desc.strip_width = std::uint32_t(
+            internal::Sweep<F, split_cell_structure, Tuning::max_generations, Tuning::cells_per_lane,
+                            Tuning::prefetch_rows, Tuning::interior_variant>::OW);
         for (int f = 0; f < Planes::n_planes; f++)
             desc.plane_elem_size[f] = Planes::elem_size(f);
         ststhip_run_info info = {};

@@ -485,8 +485,11 @@ inline int pick_chunk_rows(int out_rows, unsigned n_strips, int halo_rows, int r
         return std::min(forced, std::max(out_rows, 1));
     int cus = 256;
     ststhip_compute_units(&cus);
+    // launches running side by side (row strips of the pass driver) fill each other's tails: the tail
+    // weight shrinks by their number (fitted to chunk sweeps of Jacobi 16384^2 and HotSpot 8192^2)
+    const int side_by_side = std::max(1, ststhip_launch_concurrency());
     const double slots = double(cus) * std::max(resident_blocks, 1) * waves_per_block;
-    const double alpha = env_int("STSTHIP_TAIL_PERMILLE", 500) / 1000.0;
+    const double alpha = env_int("STSTHIP_TAIL_PERMILLE", 500) / 1000.0 / side_by_side;
     const double overhead = 2.0 * halo_rows + 8.0;
     double rows = std::sqrt(double(out_rows) * double(n_strips) * overhead / (alpha * slots));
     rows = std::max(rows, 1.0);

@@ -100,6 +100,11 @@ int ststhip_launch(const void *function, unsigned grid_x, unsigned grid_y, unsig
 int ststhip_occupancy(const void *function, unsigned block_threads, size_t shared_bytes,
                       int *blocks_per_cu);
 
+/* How many sweep launches the pass driver currently keeps in flight side by side (1 outside of
+ * ststhip_run_passes).  The launcher sizes its row chunks with it: concurrent launches share the
+ * chip and hide each other's tails, so longer chunks (fewer warm-up rows) pay. */
+int ststhip_launch_concurrency(void);
+
 /* AoS <-> per-field planes by byte geometry (the reference's scatter/gather kernels,
  * StencilStream/cuda/StencilUpdate.hpp:294-321 and :408-438).  Field f of cell i is the
  * `field_size[f]` bytes at aos + i*cell_size + field_offset[f]; plane f holds them densely.
@@ -138,6 +143,7 @@ typedef struct {
     uint32_t max_generations;    /* deepest temporal blocking compiled in                */
     uint32_t tdv_size;           /* 0 = no time-dependent value                          */
     uint32_t halo_depth_per_generation; /* ghost rows one generation consumes per side   */
+    uint32_t strip_width;        /* columns one wavefront produces at max_generations    */
 } ststhip_app_info;
 
 int ststhip_app_count(void);
@@ -189,7 +195,7 @@ typedef struct {
     uint32_t n_planes;
     uint32_t max_generations;           /* deepest blocking `sweep` accepts (powers of two up to it) */
     uint32_t halo_depth_per_generation; /* radius * n_subiterations */
-    uint32_t reserved;
+    uint32_t strip_width;               /* columns one wave produces at max_generations (0 = unknown) */
     uint64_t plane_elem_size[16];
 } ststhip_sweep_desc;
 int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc,

@@ -55,6 +55,7 @@ class AppInfo(C.Structure):
         ("max_generations", C.c_uint32),
         ("tdv_size", C.c_uint32),
         ("halo_depth_per_generation", C.c_uint32),
+        ("strip_width", C.c_uint32),
     ]
 
 
@@ -150,6 +151,7 @@ def load():
         "ststhip_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
         "ststhip_launch": [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, pp, sz, vp],
         "ststhip_occupancy": [vp, C.c_uint, sz, C.POINTER(C.c_int)],
+        "ststhip_launch_concurrency": [],
         "ststhip_scatter_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
         "ststhip_gather_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
         "ststhip_app_count": [],

@@ -76,6 +76,9 @@ template <typename F, bool SOA> struct AppAdapter {
         e.info.max_generations = Tuning::max_generations;
         e.info.tdv_size = std::is_same_v<TDV, std::monostate> ? 0 : std::uint32_t(sizeof(TDV));
         e.info.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
+        e.info.strip_width = std::uint32_t(
+            stencil::hip::internal::Sweep<F, SOA, Tuning::max_generations, Tuning::cells_per_lane,
+                                          Tuning::prefetch_rows, Tuning::interior_variant>::OW);
         e.sweep = &sweep;
         return e;
     }

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <map>
 #include <mutex>
@@ -505,6 +506,9 @@ int ststhip_occupancy(const void *function, unsigned block_threads, size_t share
     return STSTHIP_OK;
 }
 
+static thread_local int g_launch_concurrency = 1;
+int ststhip_launch_concurrency(void) { return g_launch_concurrency; }
+
 int ststhip_scatter_fields(const void *aos, size_t cell_size, size_t n_cells, int n_fields,
                            const size_t *field_offset, const size_t *field_size,
                            void *const *planes, ststhip_stream stream) {
@@ -656,8 +660,22 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
     // how many virtual strips: only worth it for grids with many rows per strip
     const std::uint64_t g_max = std::uint64_t(desc->max_generations) * desc->halo_depth_per_generation;
     int strips = stencil::hip::internal::env_int("STSTHIP_VIRTUAL_STRIPS", 0);
-    if (strips <= 0)
-        strips = (H >= 8192 && depths.size() >= 2) ? 2 : 1;
+    if (strips <= 0) {
+        // Two strips pay when one launch is at least ~1.7 residency rounds of waves (its tail then
+        // costs a sizeable share and the other strip can fill it); below that the extra band launches
+        // cost more than they win (measured: Jacobi 8192^2 -15 %, HotSpot 8192^2 +8 %, Jacobi 16384^2 +6 %).
+        strips = 1;
+        if (depths.size() >= 2 && desc->strip_width > 0) {
+            const double n_cols = std::ceil(double(dom->global_width) / desc->strip_width);
+            const double slots = double(rt().compute_units) * 16.0; // ~4 workgroups of 4 waves per CU
+            const double rows = std::sqrt(double(H) * n_cols * (2.0 * double(g_max) + 8.0) / (0.5 * slots));
+            const double waves = n_cols * double(H) / std::max(rows, 1.0);
+            if (waves >= 1.7 * slots)
+                strips = 2;
+        } else if (depths.size() >= 2 && H >= 12288 && dom->global_width >= 4096) {
+            strips = 2;
+        }
+    }
     if (profiling || H < std::uint64_t(strips) * 8 * std::max<std::uint64_t>(g_max, 1))
         strips = 1;
     strips = std::min(strips, 8);
@@ -705,6 +723,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         if (strips == 2) // unequal strips drift out of phase, so one strip's tail meets the other's bulk
             bound[1] = H * std::uint64_t(stencil::hip::internal::env_int("STSTHIP_STRIP_SKEW_PERMILLE", 400)) / 1000;
         std::vector<hipEvent_t> bands_done(strips, nullptr); // per strip: bands of the previous pass
+        g_launch_concurrency = strips;
 
         // the last pass must land in dst; the input is never written
         const void *const *from = src;
@@ -758,6 +777,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             from = const_cast<const void *const *>(to);
             iteration += depths[pass];
         }
+        g_launch_concurrency = 1;
         // join: the caller's stream continues after every strip has finished
         for (int v = 1; v < strips; v++) {
             hipEvent_t done = new_event();
@@ -827,6 +847,7 @@ int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cel
     desc.n_planes = e->info.n_planes;
     desc.max_generations = e->info.max_generations;
     desc.halo_depth_per_generation = e->info.halo_depth_per_generation;
+    desc.strip_width = e->info.strip_width;
     for (unsigned p = 0; p < e->info.n_planes; p++)
         desc.plane_elem_size[p] = e->info.plane_elem_size[p];
     AppCall call{e, tf_params, halo_cell};
