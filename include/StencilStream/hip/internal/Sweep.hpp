@@ -401,7 +401,12 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
 #pragma unroll
                             for (int cc = 0; cc < D; cc++)
                                 st[sycl::id<2>(rr, cc)] = ext[rr][k + cc];
-                        next[k] = a.f(st);
+                        // a transition function may provide a form that knows its level inside the
+                        // launch at compile time (used by fused forms whose first / last level differ)
+                        if constexpr (requires { a.f.template at_level<0, 1>(st); })
+                            next[k] = a.f.template at_level<decltype(lc)::value, S>(st);
+                        else
+                            next[k] = a.f(st);
                         if constexpr (EDGE)
                             if (!(row_in && col_in[k]))
                                 next[k] = a.halo; // out-of-grid cells never evolve

@@ -74,6 +74,12 @@ class JacobiParams(C.Structure):
     _fields_ = [("coef", C.c_float * 9)]
 
 
+class JacobiUniformParams(C.Structure):
+    """parameter block of the jacobi5uniform* kernels: the common coefficient"""
+
+    _fields_ = [("c", C.c_float)]
+
+
 class HotspotParams(C.Structure):
     _fields_ = [("Rx_1", C.c_float), ("Ry_1", C.c_float), ("Rz_1", C.c_float), ("Cap_1", C.c_float)]
 

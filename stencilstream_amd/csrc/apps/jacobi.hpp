@@ -4,6 +4,7 @@
 #pragma once
 #include <StencilStream/BaseTransitionFunction.hpp>
 #include <StencilStream/Stencil.hpp>
+#include <cstdint>
 #include <ststhip.h>
 
 namespace stencil {
@@ -63,4 +64,76 @@ template <JacobiVariant V> struct Jacobi : public BaseTransitionFunction {
 };
 
 } // namespace apps
+} // namespace stencil
+
+namespace stencil {
+namespace apps {
+
+// Jacobi5General for the case that all five coefficients are the same number c (the reference's own
+// benchmark setting, examples/jacobi/scripts/benchmark.jl:44-45).  Then every product c*x is the same float
+// no matter which neighbour uses it, so a cell can carry p = fl(c*x) through the generations instead of x:
+//     out = ((((p_N + p_W) + p_S) + p_E) + p_C)          same additions, same order, same values
+//     p_out = fl(c * out)                                  one multiplication per cell instead of five
+// Results are bit-identical to Jacobi5General (kernels.hpp:267-271); the work per cell-update drops from
+// 9 to 5 floating-point operations.  Grids enter and leave as ordinary values: the first pipeline level of
+// the first launch of a run multiplies its (raw) inputs itself, the last level of the last launch leaves
+// its sum un-multiplied.  Which launch a kernel is for is a compile-time property (FirstLaunch /
+// LastLaunch), the level inside the launch comes from the sweep (at_level), so no level carries a
+// run-time mode.  Needs halo_value = +0 and c > 0 (then c*halo = halo bit for bit); the runtime falls
+// back to Jacobi5General otherwise.
+template <bool FirstLaunch, bool LastLaunch> struct Jacobi5Uniform : public BaseTransitionFunction {
+    using Cell = float;
+    struct Block {
+        float c;
+    };
+
+    float c;
+
+    static Jacobi5Uniform from_params(Block const &b) {
+        Jacobi5Uniform j;
+        j.c = b.c;
+        return j;
+    }
+
+    // level = 0 .. levels-1 inside one launch
+    template <int level, int levels> STST_HD float at_level(Stencil<float, 1> const &s) const {
+        constexpr bool raw_inputs = FirstLaunch && level == 0;
+        constexpr bool raw_output = LastLaunch && level == levels - 1;
+        float n = s[-1][0], w = s[0][-1], so = s[1][0], e = s[0][1], x = s[0][0];
+        if constexpr (raw_inputs) {
+            n = c * n;
+            w = c * w;
+            so = c * so;
+            e = c * e;
+            x = c * x;
+        }
+        const float sum = n + w + so + e + x;
+        if constexpr (raw_output)
+            return sum;
+        else
+            return c * sum;
+    }
+
+    // one generation on its own is the original expression (first and last level at once)
+    STST_HD float operator()(Stencil<float, 1> const &s) const {
+        return c * s[-1][0] + c * s[0][-1] + c * s[1][0] + c * s[0][1] + c * s[0][0];
+    }
+};
+
+} // namespace apps
+
+namespace hip {
+template <typename F, bool SOA> struct SweepTuning;
+// With 5 flops per cell the kernel is HBM bound at 8 generations per launch; 16 generations on 2 cells
+// per lane is the measured optimum (profiles/r01_tune_jacobi_uniform.txt: K=4,T=8: 4.39, K=4,T=16: 4.95,
+// K=3,T=16: 4.92, K=2,T=16: 5.08 Tcell/s).
+template <bool FirstLaunch, bool LastLaunch>
+struct SweepTuning<apps::Jacobi5Uniform<FirstLaunch, LastLaunch>, false> {
+    static constexpr int cells_per_lane = 2;
+    static constexpr int max_generations = 16;
+    static constexpr int prefetch_rows = 4;
+    static constexpr bool interior_variant = true;
+    static constexpr int min_waves_per_simd = 1;
+};
+} // namespace hip
 } // namespace stencil

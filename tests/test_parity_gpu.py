@@ -425,6 +425,16 @@ def _two_rank_worker(rank, world, port, result_dir):
     strip.advance(0, 21)
     strip.advance(21, 8)
     np.save(os.path.join(result_dir, f"rank{rank}.npy"), strip.owned(0, torch.float32).cpu().numpy())
+    # uniform coefficients and zero halo: the product-carrying kernels, ghosts travel in product space
+    for i in range(5):
+        p.coef[i] = 0.2
+    fast = StripDomain("jacobi5general", p, np.float32(0.0).tobytes(), H, W, rank, world, "cuda:0",
+                       exchange_via_host=True)
+    assert fast.sweep.uniform is not None
+    fast.load_owned(torch.from_numpy(grid[fast.row_begin:fast.row_end].copy()).cuda())
+    fast.advance(0, 21)
+    fast.advance(21, 1)
+    np.save(os.path.join(result_dir, f"fast{rank}.npy"), fast.owned(0, torch.float32).cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -445,6 +455,9 @@ def test_two_ranks_on_one_gpu(gpu, oracle, tmp_path):
     grid = np.random.default_rng(99).random((700, 900), dtype=np.float32)
     want = oracle.jacobi("Jacobi5General", [0.2, 0.21, 0.19, 0.22, 0.18], grid, 29, halo=0.5, n_threads=8)
     got = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(2)], axis=0)
+    assert np.array_equal(bits(got), bits(want))
+    want = oracle.jacobi("Jacobi5General", [0.2] * 5, grid, 22, halo=0.0, n_threads=8)
+    got = np.concatenate([np.load(tmp_path / f"fast{r}.npy") for r in range(2)], axis=0)
     assert np.array_equal(bits(got), bits(want))
 
 
@@ -489,3 +502,34 @@ def test_empty_and_degenerate_grids(gpu, oracle):
     want = oracle.jacobi("Jacobi5General", [0.2, 0.21, 0.19, 0.22, 0.18], grid, 9, halo=0.0)
     assert np.array_equal(bits(out[:, :W]), bits(want))
     assert (out[:, W:] == -7.0).all()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (64, 64), (257, 511), (700, 300)], ids=str)
+def test_jacobi_uniform_coefficient_fast_path(gpu, oracle, monkeypatch, shape):
+    """Five equal positive coefficients and a +0 halo switch ststhip_app_run to the product-carrying
+    form (5 instead of 9 flops per cell).  It must stay bit-identical to Jacobi5General for every
+    number of generations (first / last / only launch variants) and equal the path with the switch off."""
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(shape[0] + shape[1])
+    grid = rng.random(shape, dtype=np.float32) * 3 - 1  # negative values too
+    for c in (0.2, 0.25, 1.0, 3.0e-3):
+        coef = [c] * 5
+        for n in (1, 2, 7, 8, 9, 16, 17, 41):
+            want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=0.0, n_threads=8)
+            got = run_hip(U.jacobi("Jacobi5General", coef), grid, n, halo=np.float32(0.0))
+            assert np.array_equal(bits(got), bits(want)), f"c={c} n={n}"
+        monkeypatch.setenv("STSTHIP_JACOBI_FASTPATH", "0")
+        got = run_hip(U.jacobi("Jacobi5General", coef), grid, 17, halo=np.float32(0.0))
+        monkeypatch.delenv("STSTHIP_JACOBI_FASTPATH")
+        assert np.array_equal(bits(got), bits(oracle.jacobi("Jacobi5General", coef, grid, 17, halo=0.0)))
+    # resume across calls: 8 + 9 generations with an offset
+    coef = [0.2] * 5
+    a = run_hip(U.jacobi("Jacobi5General", coef), grid, 8, halo=np.float32(0.0), offset=3)
+    b = run_hip(U.jacobi("Jacobi5General", coef), a, 9, halo=np.float32(0.0), offset=11)
+    assert np.array_equal(bits(b), bits(oracle.jacobi("Jacobi5General", coef, grid, 17, halo=0.0)))
+    # conditions not met (halo != 0, -0 halo, negative or unequal coefficients): general kernel, still exact
+    for coef, halo in (([0.2] * 5, 0.5), ([0.2] * 5, -0.0), ([-0.2] * 5, 0.0), ([0.2, 0.2, 0.2, 0.2, 0.25], 0.0)):
+        got = run_hip(U.jacobi("Jacobi5General", coef), grid, 9, halo=np.float32(halo))
+        want = oracle.jacobi("Jacobi5General", coef, grid, 9, halo=halo, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), (coef, halo)

@@ -15,7 +15,7 @@ from stencilstream_amd import capi
 def main():
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
     gens = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    prefix = sys.argv[3] if len(sys.argv) > 3 else "x_j5_"
+    prefix = sys.argv[3] if len(sys.argv) > 3 else "x_j"
     capi.init(0)
     p = capi.JacobiParams()
     for i in range(5):
@@ -27,7 +27,7 @@ def main():
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     names = ["jacobi5general"] + [a for a in capi.list_apps() if a.startswith(prefix)]
-    for wpc in (125, 250, 500, 1000, 2000):
+    for wpc in (500,):
         os.environ["STSTHIP_TAIL_PERMILLE"] = str(wpc)
         for app in names:
             capi.app_run(app, p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens, blocking=True, stream=side.cuda_stream)
