@@ -3,8 +3,8 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 torch.distributed.run with one rank per GPU.  A "step" is one StencilUpdate call of
-`--generations` generations (default 256 = 16 launches of 16 generations, so the default 4 steps are
-1024 generations, BASELINE.json's 1000 rounded up to whole launches).  Rank 0 prints ONE JSON line.
+`--generations` generations (default 252 = 21 launches of 12 generations, so the default 4 steps are
+1008 generations, BASELINE.json's 1000 rounded up to whole launches).  Rank 0 prints ONE JSON line.
 
 Metric: Gcell-updates/s = H*W*generations / time (sub-iterations not counted), the reference's
 definition (scripts/benchmark-common.jl:97-98,122).  The grid is resident in HBM before the timed
@@ -32,7 +32,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=16384, help="grid rows (per GPU) and columns")
-    ap.add_argument("--generations", type=int, default=256, help="generations per step")
+    ap.add_argument("--generations", type=int, default=252, help="generations per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-host-exchange", action="store_true",
                     help="debugging: all ranks on cuda:0, gloo process group, ghost rows through host memory")
@@ -101,7 +101,7 @@ def main():
     halo = np.float32(0.0).tobytes()
     app = os.environ.get("STSTHIP_BENCH_APP", "jacobi5general")  # tuning experiments only
     # five equal positive coefficients and a +0 halo: the runtime uses the bit-identical product-carrying
-    # form of the kernel (Jacobi5Uniform, 5 instead of 9 flops per cell, 16 generations per launch)
+    # form of the kernel (Jacobi5Uniform, 5 instead of 9 flops per cell, 12 generations per launch)
     uniform = app == "jacobi5general" and len(set(COEF)) == 1 and COEF[0] > 0 and \
         os.environ.get("STSTHIP_JACOBI_FASTPATH", "1") != "0"
     info = capi.app_info("jacobi5uniform" if uniform else app)
@@ -207,7 +207,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": ("sweep_kernel<Sweep<Jacobi5Uniform, AoS, T=16, K=2, P=4>>" if uniform
+                "kernel": ("sweep_kernel<Sweep<Jacobi5Uniform, AoS, T=12, K=3, P=4>>" if uniform
                            else "sweep_kernel<Sweep<Jacobi<General5>, AoS, T=8, K=4, P=4>>"),
                 "kernel_ms": kernel_ms,
                 "launches_timed": int(prof.n_launches),

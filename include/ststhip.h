@@ -150,8 +150,8 @@ int ststhip_app_count(void);
 int ststhip_app_info_at(int index, ststhip_app_info *info);
 int ststhip_app_find(const char *name, ststhip_app_info *info);
 
-/* Advance global rows [out_row_begin, out_row_end) by `n_generations` (1 <= n <=
- * max_generations) generations in ONE kernel launch, reading `src` and writing `dst` (arrays of
+/* Advance global rows [out_row_begin, out_row_end) by `n_generations` (max_generations or one of its
+ * repeated halvings) generations in ONE kernel launch, reading `src` and writing `dst` (arrays of
  * n_planes device pointers with identical geometry `dom`).  Rows of `dst` outside the range are
  * not touched.  Input rows [out_row_begin - g, out_row_end + g) that lie inside the global grid
  * must be present in `src`, g = n_generations * halo_depth_per_generation.  `tf_params` is the

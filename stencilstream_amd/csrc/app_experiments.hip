@@ -25,6 +25,28 @@ STSTHIP_REGISTER_APP("x_ju_k2t16p2", U3, false);
 STSTHIP_REGISTER_APP("x_ju_k4t16p2", U4, false);
 STSTHIP_REGISTER_APP("x_ju_k4t8p6", U5, false);
 STSTHIP_REGISTER_APP("x_ju_k4t8p8", U6, false);
+using V1 = Shaped<JU, 4, 12, 4>;
+using V2 = Shaped<JU, 4, 12, 2>;
+using V3 = Shaped<JU, 3, 12, 4>;
+using V4 = Shaped<JU, 2, 12, 4>;
+using V5 = Shaped<JU, 2, 24, 4>;
+STSTHIP_REGISTER_APP("x_ju_k4t12p4", V1, false);
+STSTHIP_REGISTER_APP("x_ju_k4t12p2", V2, false);
+STSTHIP_REGISTER_APP("x_ju_k3t12p4", V3, false);
+STSTHIP_REGISTER_APP("x_ju_k2t12p4", V4, false);
+STSTHIP_REGISTER_APP("x_ju_k2t24p4", V5, false);
+using W1 = Shaped<JU, 3, 10, 4>;
+using W2 = Shaped<JU, 3, 14, 4>;
+using W3 = Shaped<JU, 4, 10, 4>;
+using W4 = Shaped<JU, 3, 12, 6>;
+using W5 = Shaped<JU, 3, 12, 2>;
+using W6 = Shaped<JU, 4, 14, 4>;
+STSTHIP_REGISTER_APP("x_ju_k3t10p4", W1, false);
+STSTHIP_REGISTER_APP("x_ju_k3t14p4", W2, false);
+STSTHIP_REGISTER_APP("x_ju_k4t10p4", W3, false);
+STSTHIP_REGISTER_APP("x_ju_k3t12p6", W4, false);
+STSTHIP_REGISTER_APP("x_ju_k3t12p2", W5, false);
+STSTHIP_REGISTER_APP("x_ju_k4t14p4", W6, false);
 using U7 = Shaped<JU, 3, 16, 4>;
 using U8 = Shaped<JU, 2, 16, 6>;
 using U9 = Shaped<JU, 4, 16, 4>;

@@ -124,13 +124,13 @@ template <bool FirstLaunch, bool LastLaunch> struct Jacobi5Uniform : public Base
 
 namespace hip {
 template <typename F, bool SOA> struct SweepTuning;
-// With 5 flops per cell the kernel is HBM bound at 8 generations per launch; 16 generations on 2 cells
-// per lane is the measured optimum (profiles/r01_tune_jacobi_uniform.txt: K=4,T=8: 4.39, K=4,T=16: 4.95,
-// K=3,T=16: 4.92, K=2,T=16: 5.08 Tcell/s).
+// With 5 flops per cell the kernel is HBM bound at 8 generations per launch; 12 generations on 3 cells
+// per lane is the measured optimum (profiles/r01_tune_jacobi_uniform.txt: K=4,T=8: 4.4, K=2,T=16: 5.1,
+// K=4,T=12: 5.3, K=3,T=12: 5.5, K=3,T=16: 5.0 Tcell/s).  Launch depths: 12 and its halvings 6, 3, 1.
 template <bool FirstLaunch, bool LastLaunch>
 struct SweepTuning<apps::Jacobi5Uniform<FirstLaunch, LastLaunch>, false> {
-    static constexpr int cells_per_lane = 2;
-    static constexpr int max_generations = 16;
+    static constexpr int cells_per_lane = 3;
+    static constexpr int max_generations = 12;
     static constexpr int prefetch_rows = 4;
     static constexpr bool interior_variant = true;
     static constexpr int min_waves_per_simd = 1;

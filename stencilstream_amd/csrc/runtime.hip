@@ -577,10 +577,13 @@ static int check_domain(const AppEntry *e, const ststhip_domain *dom, std::uint6
         return fail(STSTHIP_ERR_INVALID, "pitch smaller than the grid width");
     if (out_end > dom->global_height || out_begin > out_end)
         return fail(STSTHIP_ERR_INVALID, "output rows outside the grid");
-    if (n_generations < 1 || n_generations > e->info.max_generations ||
-        (n_generations & (n_generations - 1)) != 0)
+    // compiled depths: max_generations and its repeated halvings
+    bool compiled = false;
+    for (std::uint32_t t = e->info.max_generations; t >= 1 && !compiled; t /= 2)
+        compiled = (t == n_generations);
+    if (!compiled)
         return fail(STSTHIP_ERR_INVALID,
-                    "n_generations must be a power of two up to the app's max_generations");
+                    "n_generations must be the app's max_generations or one of its repeated halvings");
     // every input row the sweep reads must be inside the buffers: this is what keeps a
     // hand-written kernel from touching memory it does not own
     const std::int64_t g = std::int64_t(n_generations) * e->info.halo_depth_per_generation;

@@ -33,7 +33,7 @@ def split_rows(total_rows, world):
 
 
 def pass_depths(n_generations, max_generations):
-    """Greedy powers of two, largest first (the depths the sweep kernels are compiled for)."""
+    """Greedy over max_generations and its repeated halvings, largest first (the compiled depths)."""
     out, remaining = [], int(n_generations)
     while remaining > 0:
         t = int(max_generations)
