@@ -74,4 +74,17 @@ struct Fdtd {
 };
 
 } // namespace apps
+
+namespace hip {
+template <typename F, bool SOA> struct SweepTuning;
+// Measured (profiles/r01_tune_shapes_apps.txt, 4608^2): K=1 with T=4,P=4: 270 / 231 (AoS / planes),
+// T=5,P=2: 314 / 244, T=6,P=2: 347 / 284, T=7,P=2: 234 (register cliff) Gcell/s.  Launch depths 6, 3, 1.
+template <bool SOA> struct SweepTuning<apps::Fdtd, SOA> {
+    static constexpr int cells_per_lane = 1;
+    static constexpr int max_generations = 6;
+    static constexpr int prefetch_rows = 2;
+    static constexpr bool interior_variant = true;
+    static constexpr int min_waves_per_simd = 1;
+};
+} // namespace hip
 } // namespace stencil

@@ -60,7 +60,7 @@ def main():
     out = []
     for name in which:
         if name == "jacobi":
-            app, H, W, gens = "jacobi5general", 16384, 16384, 200
+            app, H, W, gens = "jacobi5general", 16384, 16384, 240
             p = capi.JacobiParams()
             for i in range(5):
                 p.coef[i] = 0.2
@@ -80,7 +80,7 @@ def main():
                 cells[..., 0] = 30.0
                 pa, pb = [cells], [torch.empty_like(cells)]
         elif name in ("fdtd", "fdtd_aos"):
-            app, H, W, gens = ("fdtd_coef" if name == "fdtd" else "fdtd_coef_aos"), 4608, 4608, 100
+            app, H, W, gens = ("fdtd_coef" if name == "fdtd" else "fdtd_coef_aos"), 4608, 4608, 120
             p = capi.FdtdParams(dt=8.1e-19, t_0=3e-13, tau=1e-13, omega=7.5e14, cutoff_iteration=10 ** 9,
                                 detect_iteration=0, source_radius_squared=100.0, source_r=H / 2, source_c=W / 2,
                                 source_distance_bound=100.0 - 2 * (H / 2) ** 2, double_center_rc=float(H))
@@ -103,9 +103,9 @@ def main():
             app = name
             meta = capi.app_info(app)
             if name.startswith("x_hs_"):
-                H, W, gens, p, fill = 8192, 8192, 192, hotspot_params(8192), [30.0, 0.25]
+                H, W, gens, p, fill = 8192, 8192, 240, hotspot_params(8192), [30.0, 0.25]
             elif name.startswith("x_fd_"):
-                H, W, gens, fill = 4608, 4608, 96, [1e-4, 2e-4, 3e-4, 0.0, 1.0, 0.3, 1.0, 0.3]
+                H, W, gens, fill = 4608, 4608, 840, [1e-4, 2e-4, 3e-4, 0.0, 1.0, 0.3, 1.0, 0.3]
                 p = capi.FdtdParams(dt=8.1e-19, t_0=3e-13, tau=1e-13, omega=7.5e14, cutoff_iteration=10 ** 9,
                                     detect_iteration=0, source_radius_squared=100.0, source_r=H / 2, source_c=W / 2,
                                     source_distance_bound=100.0 - 2 * (H / 2) ** 2, double_center_rc=float(H))
