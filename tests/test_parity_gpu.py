@@ -533,3 +533,32 @@ def test_jacobi_uniform_coefficient_fast_path(gpu, oracle, monkeypatch, shape):
         got = run_hip(U.jacobi("Jacobi5General", coef), grid, 9, halo=np.float32(halo))
         want = oracle.jacobi("Jacobi5General", coef, grid, 9, halo=halo, n_threads=8)
         assert np.array_equal(bits(got), bits(want)), (coef, halo)
+
+
+def test_baseline_size_uniform_form_equals_general_kernel(gpu, monkeypatch):
+    """BASELINE config 1 exactly (16384^2, coefficients 5 x 0.2, halo 0, centred-square init): the
+    product-carrying kernel the benchmark runs and the general nine-flop kernel give the same bits."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    N, n = 16384, 25  # 12 + 12 + 1 generations: middle/first/last launch variants
+    p = capi.JacobiParams()
+    for i in range(5):
+        p.coef[i] = 0.2
+    r = torch.arange(N, device=gpu)
+    inside = (r >= N // 4) & (r < 3 * N // 4)
+    src = (inside[:, None] & inside[None, :]).to(torch.float32).contiguous()
+    src += torch.rand(N, N, device=gpu, generator=torch.Generator(device="cuda").manual_seed(1)) * 1e-3
+    fast, general = torch.empty_like(src), torch.empty_like(src)
+    dom = capi.Domain(N, N, 0, N, N)
+    halo = np.float32(0.0).tobytes()
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    capi.app_run("jacobi5general", p, halo, dom, [src.data_ptr()], [fast.data_ptr()], 0, n, blocking=True,
+                 stream=s.cuda_stream)
+    monkeypatch.setenv("STSTHIP_JACOBI_FASTPATH", "0")
+    capi.app_run("jacobi5general", p, halo, dom, [src.data_ptr()], [general.data_ptr()], 0, n, blocking=True,
+                 stream=s.cuda_stream)
+    assert torch.equal(fast, general)
+    assert float(fast.sum()) > 0
