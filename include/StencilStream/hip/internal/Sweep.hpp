@@ -405,6 +405,11 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                         // launch at compile time (used by fused forms whose first / last level differ)
                         if constexpr (requires { a.f.template at_level<0, 1>(st); })
                             next[k] = a.f.template at_level<decltype(lc)::value, S>(st);
+                        // ... or a form for cells that are not on the rim of the grid: in a wave whose
+                        // whole footprint lies inside the grid every cell that can reach the output has
+                        // 0 < row < height-1 and 0 < column < width-1 at every level
+                        else if constexpr (!EDGE && requires { a.f.interior(st); })
+                            next[k] = a.f.interior(st);
                         else
                             next[k] = a.f(st);
                         if constexpr (EDGE)

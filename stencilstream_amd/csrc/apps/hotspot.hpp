@@ -53,6 +53,20 @@ struct Hotspot : public BaseTransitionFunction {
                                           (amb_temp - old) * Rz_1);
         return HotspotCell{next, power};
     }
+
+    // The same update for a cell that is not on the rim of the grid (no edge reflection to decide);
+    // the sweep uses it in waves that lie completely inside the grid.  Same expression, same bits.
+    STST_HD Cell interior(Stencil<HotspotCell, 1> const &s) const {
+        const float amb_temp = 80.0f;
+        const float power = s[0][0].power;
+        const float old = s[0][0].temp;
+        const float top = s[-1][0].temp, bottom = s[1][0].temp;
+        const float left = s[0][-1].temp, right = s[0][1].temp;
+        const float next = old + Cap_1 * (power + (bottom + top - 2.f * old) * Ry_1 +
+                                          (right + left - 2.f * old) * Rx_1 +
+                                          (amb_temp - old) * Rz_1);
+        return HotspotCell{next, power};
+    }
 };
 
 } // namespace apps
