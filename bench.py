@@ -31,7 +31,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=16384, help="grid rows (per GPU) and columns")
+    ap.add_argument("--size", type=int, default=16384, help="grid columns, and rows per GPU unless --rows-per-gpu")
+    ap.add_argument("--rows-per-gpu", type=int, default=0,
+                    help="rows of every rank's strip (default: --size); BASELINE config 5 = --size 65536 "
+                         "--rows-per-gpu 8192 on 8 GPUs")
     ap.add_argument("--generations", type=int, default=252, help="generations per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-host-exchange", action="store_true",
@@ -94,7 +97,7 @@ def main():
     capi.init(local_rank)
     stream = torch.cuda.Stream(device)  # the stream every sweep is launched on (and timed on)
 
-    H, W, gens = args.size, args.size, args.generations
+    H, W, gens = (args.rows_per_gpu or args.size), args.size, args.generations
     p = capi.JacobiParams()
     for i, c in enumerate(COEF):
         p.coef[i] = c

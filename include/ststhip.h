@@ -211,6 +211,9 @@ typedef struct {
     float Rx_1, Ry_1, Rz_1, Cap_1;
 } ststhip_hotspot_params;
 typedef struct {
+    double Rx_1, Ry_1, Rz_1, Cap_1;
+} ststhip_hotspot_params_f64; /* "hotspot_f64" / "hotspot_f64_aos": the same formula in fp64 (an extra) */
+typedef struct {
     float dt, t_0, tau, omega;
     uint64_t cutoff_iteration, detect_iteration;
     float source_radius_squared;

@@ -35,6 +35,13 @@ class HotspotParams(C.Structure):
     _fields_ = [("Rx_1", C.c_float), ("Ry_1", C.c_float), ("Rz_1", C.c_float), ("Cap_1", C.c_float)]
 
 
+HOTSPOT_CELL_F64 = np.dtype([("temp", "<f8"), ("power", "<f8")])
+
+
+class HotspotParamsF64(C.Structure):
+    _fields_ = [("Rx_1", C.c_double), ("Ry_1", C.c_double), ("Rz_1", C.c_double), ("Cap_1", C.c_double)]
+
+
 class FdtdParams(C.Structure):
     _fields_ = [
         ("dt", C.c_float),
@@ -128,6 +135,17 @@ def hotspot(params, cells, n_iterations, iteration_offset=0, n_threads=1):
     src = np.ascontiguousarray(cells, dtype=HOTSPOT_CELL)
     out = np.empty_like(src)
     rc = lib().oracle_hotspot(
+        C.byref(params), _p(src), _p(out), _sz(src.shape[0]), _sz(src.shape[1]),
+        _sz(iteration_offset), _sz(n_iterations), C.c_int(n_threads),
+    )
+    assert rc == 0
+    return out
+
+
+def hotspot_f64(params, cells, n_iterations, iteration_offset=0, n_threads=1):
+    src = np.ascontiguousarray(cells, dtype=HOTSPOT_CELL_F64)
+    out = np.empty_like(src)
+    rc = lib().oracle_hotspot_f64(
         C.byref(params), _p(src), _p(out), _sz(src.shape[0]), _sz(src.shape[1]),
         _sz(iteration_offset), _sz(n_iterations), C.c_int(n_threads),
     )

@@ -232,6 +232,40 @@ int oracle_hotspot(const oracle_hotspot_params *p, const oracle_hotspot_cell *in
     return oracle_run(&f, in, out, H, W, &halo, iteration_offset, n_iterations, n_threads);
 }
 
+static void hotspot_f64_fn(const void *vctx, const oracle_stencil *st, void *out) {
+    /* examples/hotspot/hotspot.cpp:69-96 with FLOAT = double */
+    const oracle_hotspot_params_f64 *k = (const oracle_hotspot_params_f64 *)vctx;
+    const double amb_temp = 80.0;
+    double power = NB(st, oracle_hotspot_cell_f64, 0, 0).power;
+    double old = NB(st, oracle_hotspot_cell_f64, 0, 0).temp;
+    double top = NB(st, oracle_hotspot_cell_f64, -1, 0).temp;
+    double bottom = NB(st, oracle_hotspot_cell_f64, 1, 0).temp;
+    double left = NB(st, oracle_hotspot_cell_f64, 0, -1).temp;
+    double right = NB(st, oracle_hotspot_cell_f64, 0, 1).temp;
+    if (st->row == 0) {
+        top = old;
+    } else if (st->row == st->grid_h - 1) {
+        bottom = old;
+    }
+    if (st->col == 0) {
+        left = old;
+    } else if (st->col == st->grid_w - 1) {
+        right = old;
+    }
+    double new_temp = old + k->Cap_1 * (power + (bottom + top - 2.0 * old) * k->Ry_1 +
+                                        (right + left - 2.0 * old) * k->Rx_1 + (amb_temp - old) * k->Rz_1);
+    oracle_hotspot_cell_f64 nc = {new_temp, power};
+    *(oracle_hotspot_cell_f64 *)out = nc;
+}
+
+int oracle_hotspot_f64(const oracle_hotspot_params_f64 *p, const oracle_hotspot_cell_f64 *in,
+                       oracle_hotspot_cell_f64 *out, size_t H, size_t W, size_t iteration_offset,
+                       size_t n_iterations, int n_threads) {
+    const oracle_hotspot_cell_f64 halo = {0.0, 0.0};
+    oracle_function f = {sizeof(oracle_hotspot_cell_f64), 1, 1, 0, hotspot_f64_fn, NULL, p};
+    return oracle_run(&f, in, out, H, W, &halo, iteration_offset, n_iterations, n_threads);
+}
+
 /* ------------------------------------------------------------------ Conway */
 static void conway_fn(const void *vctx, const oracle_stencil *st, void *out) {
     /* examples/conway/conway.cpp:38-55 */

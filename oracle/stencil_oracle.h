@@ -101,6 +101,17 @@ int oracle_hotspot(const oracle_hotspot_params *p, const oracle_hotspot_cell *in
                    oracle_hotspot_cell *out, size_t H, size_t W, size_t iteration_offset,
                    size_t n_iterations, int n_threads);
 
+/* the same formula in fp64 (an extra: the reference computes in fp32) */
+typedef struct {
+    double temp, power;
+} oracle_hotspot_cell_f64;
+typedef struct {
+    double Rx_1, Ry_1, Rz_1, Cap_1;
+} oracle_hotspot_params_f64;
+int oracle_hotspot_f64(const oracle_hotspot_params_f64 *p, const oracle_hotspot_cell_f64 *in,
+                       oracle_hotspot_cell_f64 *out, size_t H, size_t W, size_t iteration_offset,
+                       size_t n_iterations, int n_threads);
+
 /* ---- Conway: examples/conway/conway.cpp:35-56 (Cell = bool, halo = false) ---- */
 int oracle_conway(const uint8_t *in, uint8_t *out, size_t H, size_t W, size_t n_iterations,
                   int n_threads);

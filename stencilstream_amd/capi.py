@@ -84,6 +84,10 @@ class HotspotParams(C.Structure):
     _fields_ = [("Rx_1", C.c_float), ("Ry_1", C.c_float), ("Rz_1", C.c_float), ("Cap_1", C.c_float)]
 
 
+class HotspotParamsF64(C.Structure):
+    _fields_ = [("Rx_1", C.c_double), ("Ry_1", C.c_double), ("Rz_1", C.c_double), ("Cap_1", C.c_double)]
+
+
 class FdtdParams(C.Structure):
     _fields_ = [
         ("dt", C.c_float),

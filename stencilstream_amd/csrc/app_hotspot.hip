@@ -5,3 +5,7 @@
 using namespace stencil::apps;
 STSTHIP_REGISTER_APP("hotspot", Hotspot, true);
 STSTHIP_REGISTER_APP("hotspot_aos", Hotspot, false);
+// the same formula in fp64 (the reference is fp32; BASELINE.json names an fp64 configuration)
+using Hotspot64 = HotspotT<double>;
+STSTHIP_REGISTER_APP("hotspot_f64", Hotspot64, true);
+STSTHIP_REGISTER_APP("hotspot_f64_aos", Hotspot64, false);

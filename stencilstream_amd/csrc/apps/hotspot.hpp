@@ -1,30 +1,33 @@
 // Rodinia HotSpot transition function, precompiled into libststhip.so.
-// Arithmetic parity: examples/hotspot/hotspot.cpp:57-97 of the reference (fp32, two-field cell with
-// the SoA opt-in tuple, reflecting edges by substituting the centre temperature, power carried
-// through unchanged, ambient temperature 80).
+// Arithmetic parity: examples/hotspot/hotspot.cpp:57-97 of the reference (two-field cell with the SoA
+// opt-in tuple, reflecting edges by substituting the centre temperature, power carried through unchanged,
+// ambient temperature 80).  The reference computes in fp32 (`typedef float FLOAT`, hotspot.cpp:38);
+// Real = double is the same formula in fp64 (BASELINE.json names an fp64 HotSpot; it is an extra here).
 #pragma once
 #include <StencilStream/BaseTransitionFunction.hpp>
 #include <StencilStream/Stencil.hpp>
 #include <ststhip.h>
 #include <tuple>
+#include <type_traits>
 
 namespace stencil {
 namespace apps {
 
-struct HotspotCell {
-    float temp;
-    float power;
-    static constexpr auto fields = std::make_tuple(&HotspotCell::temp, &HotspotCell::power);
+template <typename Real> struct HotspotCellT {
+    Real temp;
+    Real power;
+    static constexpr auto fields = std::make_tuple(&HotspotCellT::temp, &HotspotCellT::power);
 };
 
-struct Hotspot : public BaseTransitionFunction {
-    using Cell = HotspotCell;
-    using Block = ststhip_hotspot_params;
+template <typename Real> struct HotspotT : public BaseTransitionFunction {
+    using Cell = HotspotCellT<Real>;
+    using Block = std::conditional_t<std::is_same_v<Real, float>, ststhip_hotspot_params,
+                                     ststhip_hotspot_params_f64>;
 
-    float Rx_1, Ry_1, Rz_1, Cap_1;
+    Real Rx_1, Ry_1, Rz_1, Cap_1;
 
-    static Hotspot from_params(Block const &p) {
-        Hotspot h;
+    static HotspotT from_params(Block const &p) {
+        HotspotT h;
         h.Rx_1 = p.Rx_1;
         h.Ry_1 = p.Ry_1;
         h.Rz_1 = p.Rz_1;
@@ -32,12 +35,12 @@ struct Hotspot : public BaseTransitionFunction {
         return h;
     }
 
-    STST_HD Cell operator()(Stencil<HotspotCell, 1> const &s) const {
-        const float amb_temp = 80.0f;
-        const float power = s[0][0].power;
-        const float old = s[0][0].temp;
-        float top = s[-1][0].temp, bottom = s[1][0].temp;
-        float left = s[0][-1].temp, right = s[0][1].temp;
+    STST_HD Cell operator()(Stencil<Cell, 1> const &s) const {
+        const Real amb_temp = Real(80.0);
+        const Real power = s[0][0].power;
+        const Real old = s[0][0].temp;
+        Real top = s[-1][0].temp, bottom = s[1][0].temp;
+        Real left = s[0][-1].temp, right = s[0][1].temp;
 
         if (s.id[0] == 0)
             top = old;
@@ -48,26 +51,29 @@ struct Hotspot : public BaseTransitionFunction {
         else if (s.id[1] == s.grid_range[1] - 1)
             right = old;
 
-        const float next = old + Cap_1 * (power + (bottom + top - 2.f * old) * Ry_1 +
-                                          (right + left - 2.f * old) * Rx_1 +
-                                          (amb_temp - old) * Rz_1);
-        return HotspotCell{next, power};
+        const Real next = old + Cap_1 * (power + (bottom + top - Real(2) * old) * Ry_1 +
+                                         (right + left - Real(2) * old) * Rx_1 +
+                                         (amb_temp - old) * Rz_1);
+        return Cell{next, power};
     }
 
     // The same update for a cell that is not on the rim of the grid (no edge reflection to decide);
     // the sweep uses it in waves that lie completely inside the grid.  Same expression, same bits.
-    STST_HD Cell interior(Stencil<HotspotCell, 1> const &s) const {
-        const float amb_temp = 80.0f;
-        const float power = s[0][0].power;
-        const float old = s[0][0].temp;
-        const float top = s[-1][0].temp, bottom = s[1][0].temp;
-        const float left = s[0][-1].temp, right = s[0][1].temp;
-        const float next = old + Cap_1 * (power + (bottom + top - 2.f * old) * Ry_1 +
-                                          (right + left - 2.f * old) * Rx_1 +
-                                          (amb_temp - old) * Rz_1);
-        return HotspotCell{next, power};
+    STST_HD Cell interior(Stencil<Cell, 1> const &s) const {
+        const Real amb_temp = Real(80.0);
+        const Real power = s[0][0].power;
+        const Real old = s[0][0].temp;
+        const Real top = s[-1][0].temp, bottom = s[1][0].temp;
+        const Real left = s[0][-1].temp, right = s[0][1].temp;
+        const Real next = old + Cap_1 * (power + (bottom + top - Real(2) * old) * Ry_1 +
+                                         (right + left - Real(2) * old) * Rx_1 +
+                                         (amb_temp - old) * Rz_1);
+        return Cell{next, power};
     }
 };
+
+using HotspotCell = HotspotCellT<float>;
+using Hotspot = HotspotT<float>;
 
 } // namespace apps
 } // namespace stencil

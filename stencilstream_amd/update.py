@@ -44,6 +44,15 @@ def hotspot(Rx_1, Ry_1, Rz_1, Cap_1, split_cell_structure=True):
     return TransitionFunction("hotspot" if split_cell_structure else "hotspot_aos", p, HOTSPOT_CELL)
 
 
+HOTSPOT_CELL_F64 = np.dtype([("temp", "<f8"), ("power", "<f8")])
+
+
+def hotspot_f64(Rx_1, Ry_1, Rz_1, Cap_1, split_cell_structure=True):
+    """HotSpot with the reference's formula evaluated in fp64 (the reference itself is fp32)."""
+    p = capi.HotspotParamsF64(Rx_1, Ry_1, Rz_1, Cap_1)
+    return TransitionFunction("hotspot_f64" if split_cell_structure else "hotspot_f64_aos", p, HOTSPOT_CELL_F64)
+
+
 def conway():
     return TransitionFunction("conway", capi.NoParams(), np.dtype("u1"))
 

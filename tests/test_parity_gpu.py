@@ -562,3 +562,24 @@ def test_baseline_size_uniform_form_equals_general_kernel(gpu, monkeypatch):
                  stream=s.cuda_stream)
     assert torch.equal(fast, general)
     assert float(fast.sum()) > 0
+
+
+@pytest.mark.parametrize("split", [True, False], ids=["planes", "aos"])
+def test_hotspot_fp64_bit_exact(gpu, oracle, split):
+    """The HotSpot formula evaluated in fp64 (BASELINE.json names an fp64 HotSpot; the reference itself
+    is fp32, examples/hotspot/hotspot.cpp:38).  Same expression in the oracle and on the GPU."""
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(64)
+    shape = (300, 517)
+    cells = np.zeros(shape, dtype=U.HOTSPOT_CELL_F64)
+    cells["temp"] = 320 + 10 * rng.random(shape)
+    cells["power"] = rng.random(shape) * 0.01
+    p32 = oracle.hotspot_params(*shape)
+    vals = [float(p32.Rx_1), float(p32.Ry_1), float(p32.Rz_1), float(p32.Cap_1)]
+    po = oracle.HotspotParamsF64(*vals)
+    for n in (1, 8, 23):
+        got = run_hip(U.hotspot_f64(*vals, split_cell_structure=split), cells, n)
+        want = oracle.hotspot_f64(po, cells, n, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"n={n}"
+    assert np.abs(want["temp"] - cells["temp"]).max() > 0

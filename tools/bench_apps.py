@@ -51,7 +51,8 @@ def run(app, params, halo, planes_a, planes_b, H, W, gens, stream, reps=3):
 
 
 def main():
-    which = sys.argv[1:] or ["jacobi", "hotspot", "hotspot_aos", "fdtd", "fdtd_aos", "conway"]
+    which = sys.argv[1:] or ["jacobi", "hotspot", "hotspot_aos", "hotspot_f64", "hotspot_f64_aos", "fdtd", "fdtd_aos",
+                             "conway"]
     if which == ["experiments"]:
         which = ["hotspot", "fdtd", "fdtd_aos", "conway"] + [a for a in capi.list_apps() if a.startswith(("x_hs_", "x_fd_", "x_cw_"))]
     capi.init(0)
@@ -77,6 +78,20 @@ def main():
                 pa, pb = [temp, power], [torch.empty_like(temp), torch.empty_like(power)]
             else:
                 cells = torch.zeros(H, W, 2, device=dev)
+                cells[..., 0] = 30.0
+                pa, pb = [cells], [torch.empty_like(cells)]
+        elif name in ("hotspot_f64", "hotspot_f64_aos"):
+            app, H, W, gens = name, 8192, 8192, 200
+            p32 = hotspot_params(H)
+            p = capi.HotspotParamsF64(p32.Rx_1, p32.Ry_1, p32.Rz_1, p32.Cap_1)
+            halo = np.zeros(2, np.float64).tobytes()
+            if name == "hotspot_f64":
+                temp = torch.full((H, W), 30.0, device=dev, dtype=torch.float64)
+                power = torch.zeros(H, W, device=dev, dtype=torch.float64)
+                power[H // 4 - 1:3 * H // 4, W // 4 - 1:3 * W // 4] = 0.5
+                pa, pb = [temp, power], [torch.empty_like(temp), torch.empty_like(power)]
+            else:
+                cells = torch.zeros(H, W, 2, device=dev, dtype=torch.float64)
                 cells[..., 0] = 30.0
                 pa, pb = [cells], [torch.empty_like(cells)]
         elif name in ("fdtd", "fdtd_aos"):
