@@ -423,9 +423,6 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                         win[lc][oldest][k] = cur[k];
                         cur[k] = next[k];
                     }
-#ifdef STST_LEVEL_BARRIER
-                    __builtin_amdgcn_sched_barrier(0); // keep levels from interleaving (register pressure)
-#endif
                 });
 
                 const int j = y - G; // row leaving the last level

@@ -4,6 +4,7 @@
 #include "api_tests.hpp"
 #include <StencilStream/BaseTransitionFunction.hpp>
 #include <StencilStream/cuda/StencilUpdate.hpp>
+#include <StencilStream/cuda/internal/Helpers.hpp>
 #include <apps/conway.hpp>
 
 using namespace stencil;
@@ -72,7 +73,25 @@ static void test_zero_iterations_alias() {
     REQUIRE(in[1][1] == true);
 }
 
+static void test_field_buffers() {
+    // cuda/internal/Helpers.hpp:37-67: one typed plane per field, zipped iteration
+    auto buffers = cuda::internal::alloc_field_buffers<apps::SelfCheckCell>(1000);
+    REQUIRE(buffers.size() == 1000);
+    int visited = 0;
+    cuda::internal::for_each_in_two_tuples(buffers.pointers(), apps::SelfCheckCell::fields,
+                                           [&](auto *plane, auto member) {
+                                               REQUIRE(plane != nullptr);
+                                               apps::SelfCheckCell probe{};
+                                               static_assert(sizeof(*plane) == sizeof(probe.*member));
+                                               visited++;
+                                           });
+    REQUIRE(visited == 5);
+    auto set = buffers.plane_set();
+    REQUIRE(set.plane[0] == std::get<0>(buffers.pointers()) && set.plane[4] == std::get<4>(buffers.pointers()));
+}
+
 int main() {
+    test_field_buffers();
     api_tests::test_stencil_indexing();
     api_tests::test_grid<hip::Grid<sycl::id<2>>>(128, 128);
     api_tests::test_grid<hip::Grid<sycl::id<2>>>(3, 17);
