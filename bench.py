@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-host-exchange", action="store_true",
                     help="debugging: all ranks on cuda:0, gloo process group, ghost rows through host memory")
+    ap.add_argument("--strip-domain", action="store_true",
+                    help="debugging: drive the sweep through the multi-GPU strip driver even with one rank")
     ap.add_argument("--single-strip", action="store_true",
                     help="one full-grid launch per pass (no row strips on side streams); used for profiling")
     ap.add_argument("--cpu-size", type=int, default=8192)
@@ -109,7 +111,7 @@ def main():
         os.environ.get("STSTHIP_JACOBI_FASTPATH", "1") != "0"
     info = capi.app_info("jacobi5uniform" if uniform else app)
 
-    if world == 1:
+    if world == 1 and not args.strip_domain:
         src = init_grid_device(torch, H, W, 0, H, device)
         dst = torch.empty_like(src)
         dom = capi.Domain(H, W, 0, H, W)
@@ -126,7 +128,9 @@ def main():
 
         from stencilstream_amd.dist import StripDomain
 
-        if args.debug_host_exchange:
+        if world == 1:
+            pass  # --strip-domain: no process group, no neighbours
+        elif args.debug_host_exchange:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
@@ -138,7 +142,7 @@ def main():
         def step():
             strip.advance(0, gens)
 
-        barrier = dist.barrier
+        barrier = dist.barrier if world > 1 else (lambda: None)
 
     for _ in range(args.warmup):
         step()
@@ -184,7 +188,7 @@ def main():
                 "decomposition": "none" if world == 1 else f"{world} row strips of {H} rows, RCCL ghost rows",
             },
         }
-        if world == 1:
+        if world == 1 and not args.strip_domain:
             # The dominant (only) kernel, measured live: full-grid launches (one row strip) of T
             # generations, HIP events around every launch on the launch stream.
             saved = os.environ.get("STSTHIP_VIRTUAL_STRIPS")
@@ -225,7 +229,8 @@ def main():
                 except Exception:
                     pass
             # the general-coefficient kernel (nine flops per cell), same grid, coefficients that differ
-            if uniform:
+            extras = os.environ.get("STSTHIP_BENCH_MINIMAL", "0") == "0"  # profiling runs skip the extra legs
+            if uniform and extras:
                 q = capi.JacobiParams()
                 for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
                     q.coef[i] = c
@@ -240,6 +245,8 @@ def main():
             # the same kernel with fused multiply-adds (not bit-identical to the reference's cpu backend;
             # reported for information only, never as `value`)
             try:
+                if not extras:
+                    raise capi.StsthipError(0, "skipped", "")
                 capi.app_info(app + "_fma")
                 capi.app_run(app + "_fma", p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0, gens, blocking=True,
                              stream=stream.cuda_stream)

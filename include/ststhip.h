@@ -104,6 +104,14 @@ int ststhip_occupancy(const void *function, unsigned block_threads, size_t share
  * ststhip_run_passes).  The launcher sizes its row chunks with it: concurrent launches share the
  * chip and hide each other's tails, so longer chunks (fewer warm-up rows) pay. */
 int ststhip_launch_concurrency(void);
+/* A host that runs row-range sweeps side by side itself (the multi-GPU strip driver,
+ * stencilstream_amd/dist.py) states their number here for the calling thread; 1 resets it. */
+int ststhip_set_launch_concurrency(int n_launches_side_by_side);
+/* Into how many row strips (1 or 2) a caller that advances `rows` x `width` cells of `app` for
+ * `n_passes` launches should split them, each strip on its own stream and coupled to its
+ * neighbours through halo-deep boundary bands only: the rule ststhip_run_passes applies to a whole
+ * grid, for callers that drive ststhip_app_sweep themselves.  Returns 1 for unknown apps. */
+int ststhip_suggest_row_strips(const char *app, uint64_t rows, uint64_t width, uint64_t n_passes);
 
 /* AoS <-> per-field planes by byte geometry (the reference's scatter/gather kernels,
  * StencilStream/cuda/StencilUpdate.hpp:294-321 and :408-438).  Field f of cell i is the

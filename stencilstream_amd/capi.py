@@ -162,6 +162,8 @@ def load():
         "ststhip_launch": [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, pp, sz, vp],
         "ststhip_occupancy": [vp, C.c_uint, sz, C.POINTER(C.c_int)],
         "ststhip_launch_concurrency": [],
+        "ststhip_set_launch_concurrency": [C.c_int],
+        "ststhip_suggest_row_strips": [C.c_char_p, u64, u64, u64],
         "ststhip_scatter_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
         "ststhip_gather_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
         "ststhip_app_count": [],
@@ -289,6 +291,16 @@ def app_run(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, iteration_offse
         f"ststhip_app_run({app})",
     )
     return info
+
+
+def set_launch_concurrency(n):
+    """Number of row-range sweeps the caller keeps in flight side by side (chunk sizing hint)."""
+    check(load().ststhip_set_launch_concurrency(int(n)), "ststhip_set_launch_concurrency")
+
+
+def suggest_row_strips(app, rows, width, n_passes):
+    """1 or 2: row strips (on separate streams) the pass driver would use for such a grid."""
+    return int(load().ststhip_suggest_row_strips(app.encode(), int(rows), int(width), int(n_passes)))
 
 
 def scatter_fields(aos_ptr, cell_size, n_cells, offsets, sizes, plane_ptrs, stream=0):

@@ -508,6 +508,34 @@ int ststhip_occupancy(const void *function, unsigned block_threads, size_t share
 
 static thread_local int g_launch_concurrency = 1;
 int ststhip_launch_concurrency(void) { return g_launch_concurrency; }
+int ststhip_set_launch_concurrency(int n) {
+    g_launch_concurrency = std::min(std::max(n, 1), 8);
+    return STSTHIP_OK;
+}
+
+// Two row strips pay when one launch is at least ~1.7 residency rounds of waves (its tail then costs a
+// sizeable share and the other strip can fill it); below that the extra band launches cost more than
+// they win (measured: Jacobi 8192^2 -15 %, HotSpot 8192^2 +8 %, Jacobi 16384^2 +6 %).
+static int suggest_row_strips(std::uint64_t rows, std::uint64_t width, std::uint32_t strip_width,
+                              std::uint64_t g_max, std::uint64_t n_passes) {
+    int strips = stencil::hip::internal::env_int("STSTHIP_VIRTUAL_STRIPS", 0);
+    if (strips <= 0) {
+        strips = 1;
+        if (n_passes >= 2 && strip_width > 0) {
+            const double n_cols = std::ceil(double(width) / strip_width);
+            const double slots = double(rt().compute_units) * 16.0; // ~4 workgroups of 4 waves per CU
+            const double chunk = std::sqrt(double(rows) * n_cols * (2.0 * double(g_max) + 8.0) / (0.5 * slots));
+            const double waves = n_cols * double(rows) / std::max(chunk, 1.0);
+            if (waves >= 1.7 * slots)
+                strips = 2;
+        } else if (n_passes >= 2 && rows >= 12288 && width >= 4096) {
+            strips = 2;
+        }
+    }
+    if (rows < std::uint64_t(strips) * 8 * std::max<std::uint64_t>(g_max, 1))
+        strips = 1;
+    return std::min(strips, 8);
+}
 
 int ststhip_scatter_fields(const void *aos, size_t cell_size, size_t n_cells, int n_fields,
                            const size_t *field_offset, const size_t *field_size,
@@ -662,26 +690,8 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
 
     // how many virtual strips: only worth it for grids with many rows per strip
     const std::uint64_t g_max = std::uint64_t(desc->max_generations) * desc->halo_depth_per_generation;
-    int strips = stencil::hip::internal::env_int("STSTHIP_VIRTUAL_STRIPS", 0);
-    if (strips <= 0) {
-        // Two strips pay when one launch is at least ~1.7 residency rounds of waves (its tail then
-        // costs a sizeable share and the other strip can fill it); below that the extra band launches
-        // cost more than they win (measured: Jacobi 8192^2 -15 %, HotSpot 8192^2 +8 %, Jacobi 16384^2 +6 %).
-        strips = 1;
-        if (depths.size() >= 2 && desc->strip_width > 0) {
-            const double n_cols = std::ceil(double(dom->global_width) / desc->strip_width);
-            const double slots = double(rt().compute_units) * 16.0; // ~4 workgroups of 4 waves per CU
-            const double rows = std::sqrt(double(H) * n_cols * (2.0 * double(g_max) + 8.0) / (0.5 * slots));
-            const double waves = n_cols * double(H) / std::max(rows, 1.0);
-            if (waves >= 1.7 * slots)
-                strips = 2;
-        } else if (depths.size() >= 2 && H >= 12288 && dom->global_width >= 4096) {
-            strips = 2;
-        }
-    }
-    if (profiling || H < std::uint64_t(strips) * 8 * std::max<std::uint64_t>(g_max, 1))
-        strips = 1;
-    strips = std::min(strips, 8);
+    int strips = profiling ? 1
+                           : suggest_row_strips(H, dom->global_width, desc->strip_width, g_max, depths.size());
 
     if (depths.empty()) {
         for (unsigned p = 0; p < n_planes && rc == STSTHIP_OK; p++)
@@ -851,6 +861,15 @@ int app_sweep_trampoline(void *ctx, const ststhip_domain *dom, const void *const
                               n_generations, stream);
 }
 } // namespace
+
+int ststhip_suggest_row_strips(const char *app, uint64_t rows, uint64_t width, uint64_t n_passes) {
+    const AppEntry *e = find_app(app);
+    if (!e || ststhip_init(-1) != STSTHIP_OK)
+        return 1;
+    return suggest_row_strips(rows, width, e->info.strip_width,
+                              std::uint64_t(e->info.max_generations) * e->info.halo_depth_per_generation,
+                              n_passes);
+}
 
 int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cell,
                     const ststhip_domain *dom, const void *const *src, void *const *dst,

@@ -5,12 +5,19 @@ New functionality relative to the reference (it has no spatial decomposition, SU
 
 Every rank owns `rows_owned` consecutive rows and keeps them in a buffer with `g_max` ghost rows on
 each side.  One pass = one kernel launch of T generations (temporal blocking) and consumes
-g = T * radius * n_subiterations ghost rows per side, so ghosts are exchanged once per pass:
+g = T * radius * n_subiterations ghost rows per side, so ghosts are exchanged once per pass.
 
-    comm stream   : wait(boundary rows of pass p-1) -> send/recv g rows with rank-1 / rank+1 (RCCL p2p over xGMI)
-    compute stream: wait(ghosts of pass p) -> boundary bands of pass p -> [event] -> interior of pass p
+Inside a rank the owned rows are split once more into V sub-strips (V = 1 or 2, the rule of the
+single-GPU pass driver), each advancing on its own stream.  A sub-strip sweeps its two g-row
+boundary bands first and its interior afterwards; neighbouring sub-strips are coupled only through
+"the bands of the previous pass are done" events, so the ragged tail of one sub-strip's launch
+overlaps the next launches of the other.  The outermost bands are the rows the neighbouring ranks
+need:
 
-so the exchange for pass p+1 runs concurrently with the interior sweep of pass p.  There is no
+    sub-strip v   : wait(neighbour bands of pass p-1 | ghosts of pass p) -> bands of pass p -> [event] -> interior of pass p
+    comm stream   : wait(outermost bands of pass p) -> send/recv g rows with rank-1 / rank+1 (RCCL p2p over xGMI) -> [ghosts of pass p+1]
+
+so the exchange for pass p+1 runs concurrently with the interiors of pass p.  There is no
 collective on the data path.  The sweep itself is libststhip.so (ststhip_app_sweep); tests inject a
 CPU sweep to exercise this logic with the gloo backend.
 """
@@ -68,6 +75,13 @@ class HipSweep:
         self.first_iteration = int(iteration_offset)
         self.last_iteration = int(iteration_offset) + int(n_generations) - 1
 
+    def suggest_sub_strips(self, rows, width, n_passes):
+        return capi.suggest_row_strips("jacobi5uniform" if self.uniform is not None else self.app, rows, width,
+                                       n_passes)
+
+    def side_by_side(self, n):
+        capi.set_launch_concurrency(n)
+
     def __call__(self, src, dst, dom, out_begin, out_end, iteration, depth, stream):
         app, params = self.app, self.tf_params
         if self.uniform is not None and self.first_iteration is not None:
@@ -85,7 +99,7 @@ class StripDomain:
     """The rows of one rank plus ghost rows, double buffered."""
 
     def __init__(self, app, tf_params, halo_bytes, total_rows, width, rank, world, device, cell_dtype=None,
-                 sweep=None, group=None, min_rows_check=True, exchange_via_host=False):
+                 sweep=None, group=None, min_rows_check=True, exchange_via_host=False, sub_strips=None):
         self.sweep = sweep if sweep is not None else HipSweep(app, tf_params, halo_bytes)
         self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
         self.total_rows, self.width = int(total_rows), int(width)
@@ -111,6 +125,9 @@ class StripDomain:
             self.comm_stream = torch.cuda.Stream(self.device)
         else:
             self.compute_stream = self.comm_stream = None
+        # sub-strips of the owned rows (None: the pass driver's rule decides per advance())
+        self.sub_strips = sub_strips
+        self.side_streams = []
         self.dom = capi.Domain(self.total_rows, self.width, self.row_origin, self.local_rows, self.width)
         self.n_launches = 0
 
@@ -166,64 +183,107 @@ class StripDomain:
         return strip_rank if self.group is None else dist.get_global_rank(self.group, strip_rank)
 
     # ---- time stepping -------------------------------------------------------------------
+    def _sub_strip_bounds(self, n_passes):
+        """Row boundaries of the sub-strips of the owned rows, and the stream each one runs on."""
+        a, b = self.row_begin, self.row_end
+        v = self.sub_strips
+        if v is None:
+            suggest = getattr(self.sweep, "suggest_sub_strips", None)
+            v = suggest(b - a, self.width, n_passes) if (suggest and self.on_gpu) else 1
+        v = max(1, min(int(v), 8))
+        while v > 1 and (b - a) < v * 2 * max(self.g_max, 1):
+            v -= 1  # every sub-strip keeps at least its two bands
+        if v == 2:
+            # unequal strips drift out of phase, so one strip's tail meets the other's bulk
+            bounds = [a, a + (b - a) * 2 // 5, b]
+        else:
+            bounds = [a + (b - a) * i // v for i in range(v + 1)]
+        lanes = [self.compute_stream] * v
+        if self.on_gpu:
+            while len(self.side_streams) < v - 1:
+                self.side_streams.append(torch.cuda.Stream(self.device))
+            lanes = [self.compute_stream] + self.side_streams[:v - 1]
+        return bounds, lanes
+
     def advance(self, iteration_offset, n_generations):
         """Advance the whole (distributed) grid by n_generations generations.
 
-        Per pass, on two streams:
-            comm stream   : wait(interior of pass p-1) -> boundary bands of pass p -> exchange for pass p+1
-            compute stream: wait(bands of pass p-1)    -> interior of pass p
-        Bands and interior of one pass both read the complete result of the previous pass and write
-        disjoint rows, so they run concurrently; the exchange only moves rows the bands produced.
+        Per pass p (buffers ping-pong; `g` = halo rows of the pass):
+            sub-strip v (own stream): wait(bands of v-1, v+1 in pass p-1; outermost: ghosts of pass p)
+                                      -> top band, bottom band -> [bands event] -> interior
+            comm stream            : wait(bands events of the outermost sub-strips) -> exchange for pass p+1
+        A band reads rows up to 2g into its own strip and g into the neighbour, all of the previous
+        pass; bands and interior of one pass write disjoint rows.
         """
         depths = pass_depths(n_generations, self.sweep.max_generations)
+        if not depths:
+            return None
         iteration = int(iteration_offset)
-        a, b = self.row_begin, self.row_end
         cs, ms = self.compute_stream, self.comm_stream
         gpu = self.on_gpu
+        hpg = self.sweep.halo_per_generation
         if hasattr(self.sweep, "begin_run"):
             self.sweep.begin_run(iteration_offset, n_generations)
+        bounds, lanes = self._sub_strip_bounds(len(depths))
+        n_sub = len(bounds) - 1
+        has_up, has_down = self.rank > 0, self.rank + 1 < self.world
+        if hasattr(self.sweep, "side_by_side"):
+            self.sweep.side_by_side(n_sub)
 
         def on_comm():
             return torch.cuda.stream(ms) if gpu else _NullContext()
 
-        if not depths:
-            return None
         if gpu:
             ms.wait_stream(cs)  # everything queued so far (previous advance, load_owned)
+            for lane in lanes[1:]:
+                lane.wait_stream(cs)
         with on_comm():
-            self._exchange(self.planes[self.current], depths[0] * self.sweep.halo_per_generation)
-        interior_done = bands_done = None
+            self._exchange(self.planes[self.current], depths[0] * hpg)
+            ghosts_ready = ms.record_event() if gpu and self.world > 1 else None
+        bands_done = [None] * n_sub
         for i, depth in enumerate(depths):
-            g = depth * self.sweep.halo_per_generation
+            g = depth * hpg
             src, dst = self.planes[self.current], self.planes[self.current ^ 1]
-            # a band is only needed where there is a neighbour that waits for it
-            top_end = min(a + g, b) if self.rank > 0 else a
-            bot_begin = max(b - g, top_end) if self.rank + 1 < self.world else b
-            # boundary bands, then the exchange that only needs them
-            with on_comm():
-                if gpu and interior_done is not None:
-                    ms.wait_event(interior_done)
-                if a < top_end:
-                    self.sweep(src, dst, self.dom, a, top_end, iteration, depth, ms)
+            bands_now = [None] * n_sub
+            for v in range(n_sub):
+                va, vb, lane = bounds[v], bounds[v + 1], lanes[v]
+                up = v > 0 or has_up            # somebody above needs (and feeds) my top rows
+                down = v + 1 < n_sub or has_down
+                if gpu:
+                    if v > 0 and bands_done[v - 1] is not None:
+                        lane.wait_event(bands_done[v - 1])
+                    if v + 1 < n_sub and bands_done[v + 1] is not None:
+                        lane.wait_event(bands_done[v + 1])
+                    if ghosts_ready is not None and ((v == 0 and has_up) or (v == n_sub - 1 and has_down)):
+                        lane.wait_event(ghosts_ready)
+                top_end = min(va + g, vb) if up else va
+                bot_begin = max(vb - g, top_end) if down else vb
+                if va < top_end:
+                    self.sweep(src, dst, self.dom, va, top_end, iteration, depth, lane)
                     self.n_launches += 1
-                if bot_begin < b:
-                    self.sweep(src, dst, self.dom, bot_begin, b, iteration, depth, ms)
+                if bot_begin < vb:
+                    self.sweep(src, dst, self.dom, bot_begin, vb, iteration, depth, lane)
                     self.n_launches += 1
-                new_bands_done = ms.record_event() if gpu else None
-                if i + 1 < len(depths):
-                    self._exchange(dst, depths[i + 1] * self.sweep.halo_per_generation)
-            # interior, concurrently
-            if gpu and bands_done is not None:
-                cs.wait_event(bands_done)
-            if top_end < bot_begin:
-                self.sweep(src, dst, self.dom, top_end, bot_begin, iteration, depth, cs)
-                self.n_launches += 1
-            interior_done = cs.record_event() if gpu else None
-            bands_done = new_bands_done
+                bands_now[v] = lane.record_event() if gpu else None
+                if top_end < bot_begin:
+                    self.sweep(src, dst, self.dom, top_end, bot_begin, iteration, depth, lane)
+                    self.n_launches += 1
+            if i + 1 < len(depths) and self.world > 1:
+                with on_comm():
+                    if gpu:
+                        ms.wait_event(bands_now[0])
+                        ms.wait_event(bands_now[n_sub - 1])
+                    self._exchange(dst, depths[i + 1] * hpg)
+                    ghosts_ready = ms.record_event() if gpu else None
+            bands_done = bands_now
             self.current ^= 1
             iteration += depth
         if gpu:
+            for lane in lanes[1:]:
+                cs.wait_stream(lane)
             cs.wait_stream(ms)  # the compute stream is the one callers synchronise with
+        if hasattr(self.sweep, "side_by_side"):
+            self.sweep.side_by_side(1)
         return None
 
 

@@ -53,7 +53,7 @@ class OracleSweep:
         self.calls.append((out_begin, out_end, depth))
 
 
-def worker(rank, world, port, kind, H, W, gens, seed, result_dir):
+def worker(rank, world, port, kind, H, W, gens, seed, result_dir, sub_strips=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -69,7 +69,7 @@ def worker(rank, world, port, kind, H, W, gens, seed, result_dir):
     else:
         grid = (rng.random((H, W)) < 0.4).astype(np.uint8)
         sweep = OracleSweep("conway")
-    strip = StripDomain(None, None, None, H, W, rank, world, "cpu", sweep=sweep)
+    strip = StripDomain(None, None, None, H, W, rank, world, "cpu", sweep=sweep, sub_strips=sub_strips)
     a, b = strip.row_begin, strip.row_end
     strip.load_owned(torch.from_numpy(grid[a:b].copy()))
     done = 0
@@ -82,7 +82,23 @@ def worker(rank, world, port, kind, H, W, gens, seed, result_dir):
     # (at most one halo depth of rows) next to a neighbour
     first = sweep.calls[0]
     assert first[1] - first[0] <= sweep.max_generations * sweep.halo_per_generation
-    assert (first[0] == a and rank > 0) or (first[1] == b and rank + 1 < world)
+    if sub_strips in (None, 1):
+        assert (first[0] == a and rank > 0) or (first[1] == b and rank + 1 < world)
+    # every pass covers the owned rows exactly once, whatever the sub-strips
+    depths = [d for chunk in gens for d in __import__("stencilstream_amd.dist", fromlist=["x"]).pass_depths(
+        chunk, sweep.max_generations)]
+    at = 0
+    for depth in depths:
+        rows = []
+        while sum(e - s for s, e in rows) < b - a:
+            s0, e0, d0 = sweep.calls[at]
+            assert d0 == depth
+            rows.append((s0, e0))
+            at += 1
+        rows.sort()
+        assert rows[0][0] == a and rows[-1][1] == b
+        assert all(rows[i][1] == rows[i + 1][0] for i in range(len(rows) - 1))
+    assert at == len(sweep.calls)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -103,6 +119,19 @@ def test_strips_equal_whole_grid(oracle, tmp_path, world, kind, H, W, gens):
         want = oracle.conway(grid, total)
     got = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)], axis=0)
     assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+@pytest.mark.parametrize("world,sub_strips", [(2, 2), (2, 3), (3, 2)])
+def test_sub_strips_equal_whole_grid(oracle, tmp_path, world, sub_strips):
+    """Sub-strips inside a rank (the tail-overlap scheme of the single-GPU pass driver) change the
+    launch pattern only, never the result; ragged depths 4+4+1 and a resume."""
+    seed, H, W, gens = 77, 131, 37, [9, 6]
+    mp.spawn(worker, args=(world, free_port(), "jacobi", H, W, gens, seed, str(tmp_path), sub_strips),
+             nprocs=world, join=True)
+    grid = np.random.default_rng(seed).random((H, W), dtype=np.float32)
+    want = oracle.jacobi("Jacobi5General", [0.2, 0.21, 0.19, 0.22, 0.18], grid, sum(gens), halo=0.0)
+    got = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)], axis=0)
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
 
 

@@ -429,7 +429,7 @@ def _two_rank_worker(rank, world, port, result_dir):
     for i in range(5):
         p.coef[i] = 0.2
     fast = StripDomain("jacobi5general", p, np.float32(0.0).tobytes(), H, W, rank, world, "cuda:0",
-                       exchange_via_host=True)
+                       exchange_via_host=True, sub_strips=2)  # two sub-strips per rank on two streams
     assert fast.sweep.uniform is not None
     fast.load_owned(torch.from_numpy(grid[fast.row_begin:fast.row_end].copy()).cuda())
     fast.advance(0, 21)

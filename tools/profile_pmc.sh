@@ -4,8 +4,8 @@ TAG="$1"; shift
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/pmc_$TAG"
 mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d "$OUT" -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --generations 64 --no-cpu-baseline > "$OUT/run.log" 2>&1
+cd /tmp && export TMPDIR=/tmp && export STSTHIP_BENCH_MINIMAL=1
+rocprofv3 --pmc "$@" --output-format csv -d "$OUT" -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --generations 120 --no-cpu-baseline --single-strip > "$OUT/run.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")
