@@ -42,13 +42,15 @@ template <typename Cell> class Grid {
         }
         std::size_t bytes() const { return extent.size() * sizeof(Cell); }
 
-        void need_host() {
+        // `overwritten`: the caller fills every cell right away (a download), so the
+        // value-initialisation a fresh grid owes its cells can be skipped
+        void need_host(bool overwritten = false) {
             if (!host) {
                 internal::ensure_runtime(-1);
                 host = static_cast<Cell *>(internal::pinned_alloc(bytes()));
-                // a fresh grid holds value-initialised cells
-                for (std::size_t i = 0; i < extent.size(); i++)
-                    new (host + i) Cell();
+                if (!overwritten)
+                    for (std::size_t i = 0; i < extent.size(); i++)
+                        new (host + i) Cell();
             }
         }
         void need_device() {
@@ -58,7 +60,7 @@ template <typename Cell> class Grid {
             }
         }
         void sync_to_host() {
-            need_host();
+            need_host(!host_valid && device_valid);
             if (!host_valid && device_valid) {
                 ststhip_stream s = internal::default_stream();
                 internal::check(ststhip_memcpy_d2h(host, device, bytes(), s), "grid download");
@@ -92,7 +94,7 @@ template <typename Cell> class Grid {
 
     void copy_from_buffer(sycl::buffer<Cell, 2> source) {
         require_same_extent(source.get_range());
-        storage->need_host();
+        storage->need_host(/*overwritten=*/true);
         std::memcpy(static_cast<void *>(storage->host), source.data(), storage->bytes());
         storage->host_valid = true;
         storage->device_valid = false;

@@ -67,7 +67,8 @@ int ststhip_compute_units(int *count);
 int ststhip_malloc(void **ptr, size_t bytes);
 int ststhip_free(void *ptr);
 int ststhip_pool_trim(void);
-/* Pinned host memory for grids' host mirrors. */
+/* Pinned host memory for grids' host mirrors.  Freed blocks are kept for reuse (pinning is slow) up
+ * to STSTHIP_HOST_CACHE_MIB (default 4096) MiB; ststhip_pool_trim releases them. */
 int ststhip_host_malloc(void **ptr, size_t bytes);
 int ststhip_host_free(void *ptr);
 

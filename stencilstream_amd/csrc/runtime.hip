@@ -48,7 +48,16 @@ struct Runtime {
     // pool: bucket size -> free blocks; live: ptr -> bucket size
     std::multimap<std::size_t, void *> free_blocks;
     std::map<void *, std::size_t> live_blocks;
+    // the same for pinned host memory (pinning hundreds of MiB costs tens of ms per allocation, and every
+    // grid a StencilUpdate returns gets a host mirror as soon as the application looks at it)
+    std::multimap<std::size_t, void *> free_host_blocks;
+    std::map<void *, std::size_t> live_host_blocks;
+    std::size_t cached_host_bytes = 0;
 };
+// free pinned blocks kept for reuse, at most (pinned memory is taken from the host's RAM)
+static std::size_t host_cache_limit() {
+    return std::size_t(stencil::hip::internal::env_int("STSTHIP_HOST_CACHE_MIB", 4096)) << 20;
+}
 static Runtime &rt() {
     static Runtime r;
     return r;
@@ -299,6 +308,10 @@ int ststhip_shutdown(void) {
     for (auto &kv : r.free_blocks)
         hipFree(kv.second);
     r.free_blocks.clear();
+    for (auto &kv : r.free_host_blocks)
+        hipHostFree(kv.second);
+    r.free_host_blocks.clear();
+    r.cached_host_bytes = 0;
     hipStreamDestroy(r.stream);
     r.stream = nullptr;
     r.up = false;
@@ -384,6 +397,10 @@ int ststhip_pool_trim(void) {
     for (auto &kv : r.free_blocks)
         hipFree(kv.second);
     r.free_blocks.clear();
+    for (auto &kv : r.free_host_blocks)
+        hipHostFree(kv.second);
+    r.free_host_blocks.clear();
+    r.cached_host_bytes = 0;
     return STSTHIP_OK;
 }
 
@@ -392,13 +409,56 @@ int ststhip_host_malloc(void **ptr, size_t bytes) {
         return fail(STSTHIP_ERR_INVALID, "null argument");
     if (int rc = ststhip_init(-1))
         return rc;
-    HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    Runtime &r = rt();
+    const std::size_t bucket = bucket_of(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> guard(r.lock);
+        auto it = r.free_host_blocks.find(bucket);
+        if (it != r.free_host_blocks.end()) {
+            *ptr = it->second;
+            r.free_host_blocks.erase(it);
+            r.cached_host_bytes -= bucket;
+            r.live_host_blocks[*ptr] = bucket;
+            return STSTHIP_OK;
+        }
+    }
+    void *p = nullptr;
+    hipError_t err = hipHostMalloc(&p, bucket, hipHostMallocDefault);
+    if (err != hipSuccess) {
+        ststhip_pool_trim();
+        err = hipHostMalloc(&p, bucket, hipHostMallocDefault);
+    }
+    if (err != hipSuccess)
+        return hip_fail(err, "hipHostMalloc");
+    std::lock_guard<std::mutex> guard(r.lock);
+    r.live_host_blocks[p] = bucket;
+    *ptr = p;
     return STSTHIP_OK;
 }
 
 int ststhip_host_free(void *ptr) {
-    if (ptr && rt().up)
-        HIP_TRY(hipHostFree(ptr));
+    if (!ptr)
+        return STSTHIP_OK;
+    Runtime &r = rt();
+    std::size_t bucket = 0;
+    {
+        std::lock_guard<std::mutex> guard(r.lock);
+        auto it = r.live_host_blocks.find(ptr);
+        if (it == r.live_host_blocks.end())
+            return fail(STSTHIP_ERR_INVALID, "ststhip_host_free: pointer not from ststhip_host_malloc");
+        bucket = it->second;
+        r.live_host_blocks.erase(it);
+        if (!r.up)
+            return STSTHIP_OK; // the HIP runtime is gone (static destruction order): nothing to release
+        if (r.cached_host_bytes + bucket <= host_cache_limit()) {
+            // Transfers are stream-ordered and the owners (hip::Grid) synchronise before the host reads or
+            // releases a mirror, so a cached block has no copy in flight.
+            r.free_host_blocks.emplace(bucket, ptr);
+            r.cached_host_bytes += bucket;
+            return STSTHIP_OK;
+        }
+    }
+    HIP_TRY(hipHostFree(ptr));
     return STSTHIP_OK;
 }
 
