@@ -378,6 +378,89 @@ def test_baseline_size_properties(gpu, oracle):
         assert np.array_equal(bits(got), bits(want)), (r0, c0)
 
 
+def test_largest_baseline_grid_windows(gpu, oracle):
+    """BASELINE config 5 grid size, Jacobi5General 65536^2 (2^32 cells, 16 GiB per buffer) on one GPU:
+    element offsets exceed 32 bits.  Windows at the far corners / edges and inside must equal the oracle on
+    the window plus a margin of n cells; the uniform-coefficient path (product-carrying kernels, 12
+    generations per launch, two row strips) must equal the general kernel fed with the same coefficients
+    through STSTHIP_JACOBI_FASTPATH=0 on sampled windows."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    N, n = 65536, 25  # depths 12 + 12 + 1 (uniform) and 8 + 8 + 8 + 1 (general)
+    free, _total = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs 3 x 16 GiB of HBM")
+    p = capi.JacobiParams()
+    for i in range(5):
+        p.coef[i] = 0.2
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    src = torch.empty(N, N, device=gpu)
+    for r in range(0, N, 8192):  # slabs keep the generator's temporaries small
+        src[r:r + 8192] = torch.rand(8192, N, device=gpu, generator=gen)
+    dst = torch.empty_like(src)
+    dom = capi.Domain(N, N, 0, N, N)
+    halo = np.float32(0.0).tobytes()
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    info = capi.app_run("jacobi5general", p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 3, n, blocking=True,
+                        stream=s.cuda_stream)
+    assert info.n_launches >= 3
+    m, w = n, 64
+    spots = ((0, 0), (0, N - w), (N - w, 0), (N - w, N - w), (N // 2, N // 2), (N - w, 40000), (33333, N - w),
+             (32768 - 32, 32768 - 32), (26214 - 32, 1000))  # 26214 = the boundary between the two row strips
+    for r0, c0 in spots:
+        ra, rb = max(0, r0 - m), min(N, r0 + w + m)
+        ca, cb = max(0, c0 - m), min(N, c0 + w + m)
+        window = src[ra:rb, ca:cb].cpu().numpy()
+        ref = oracle.jacobi("Jacobi5General", [0.2] * 5, window, n, halo=0.0)
+        got = dst[r0:r0 + w, c0:c0 + w].cpu().numpy()
+        want = ref[r0 - ra:r0 - ra + w, c0 - ca:c0 - ca + w]
+        assert np.array_equal(bits(got), bits(want)), (r0, c0)
+    # checksum of per-slab checksums against the general kernel (9 flops per cell, other launch depths)
+    os.environ["STSTHIP_JACOBI_FASTPATH"] = "0"
+    try:
+        sums = [dst[r:r + 8192].view(torch.int32).sum(dtype=torch.int64).item() for r in range(0, N, 8192)]
+        capi.app_run("jacobi5general", p, halo, dom, [src.data_ptr()], [dst.data_ptr()], 3, n, blocking=True,
+                     stream=s.cuda_stream)
+        again = [dst[r:r + 8192].view(torch.int32).sum(dtype=torch.int64).item() for r in range(0, N, 8192)]
+    finally:
+        del os.environ["STSTHIP_JACOBI_FASTPATH"]
+    assert sums == again
+    del src, dst
+    torch.cuda.empty_cache()
+    capi.load().ststhip_pool_trim()
+
+
+def test_strip_driver_at_eight_gpu_shape(gpu, oracle):
+    """The per-GPU shape of BASELINE config 5 (65536 columns, 8192-row strips) through the multi-GPU strip
+    driver with one rank: far-column windows against the oracle."""
+    import torch
+
+    from stencilstream_amd import capi
+    from stencilstream_amd.dist import StripDomain
+
+    H, W, n = 8192, 65536, 13
+    p = capi.JacobiParams()
+    coef = [0.2, 0.21, 0.19, 0.22, 0.18]
+    for i, c in enumerate(coef):
+        p.coef[i] = c
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    grid = torch.rand(H, W, device=gpu, generator=gen)
+    strip = StripDomain("jacobi5general", p, np.float32(0.25).tobytes(), H, W, 0, 1, gpu, sub_strips=2)
+    strip.load_owned(grid)
+    strip.advance(0, n)
+    out = strip.owned(0, torch.float32)
+    m, w = n, 64
+    for r0, c0 in ((0, 0), (0, W - w), (H - w, W - w), (H * 2 // 5 - 32, 30000), (4000, W // 2)):
+        ra, rb = max(0, r0 - m), min(H, r0 + w + m)
+        ca, cb = max(0, c0 - m), min(W, c0 + w + m)
+        ref = oracle.jacobi("Jacobi5General", coef, grid[ra:rb, ca:cb].cpu().numpy(), n, halo=0.25)
+        got = out[r0:r0 + w, c0:c0 + w].cpu().numpy()
+        assert np.array_equal(bits(got), bits(ref[r0 - ra:r0 - ra + w, c0 - ca:c0 - ca + w])), (r0, c0)
+
+
 @pytest.mark.parametrize("strips,skew", [(2, 400), (2, 900), (3, 500), (5, 500)])
 def test_virtual_strips_small_grid(gpu, oracle, monkeypatch, strips, skew):
     """The pass driver's row strips on separate streams (normally only used for tall grids), forced on
