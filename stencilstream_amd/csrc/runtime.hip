@@ -299,20 +299,20 @@ int ststhip_shutdown(void) {
     std::lock_guard<std::mutex> guard(r.lock);
     if (!r.up)
         return STSTHIP_OK;
-    hipStreamSynchronize(r.stream);
+    (void)hipStreamSynchronize(r.stream);
     for (hipStream_t extra : side_streams()) {
-        hipStreamSynchronize(extra);
-        hipStreamDestroy(extra);
+        (void)hipStreamSynchronize(extra);
+        (void)hipStreamDestroy(extra);
     }
     side_streams().clear();
     for (auto &kv : r.free_blocks)
-        hipFree(kv.second);
+        (void)hipFree(kv.second);
     r.free_blocks.clear();
     for (auto &kv : r.free_host_blocks)
-        hipHostFree(kv.second);
+        (void)hipHostFree(kv.second);
     r.free_host_blocks.clear();
     r.cached_host_bytes = 0;
-    hipStreamDestroy(r.stream);
+    (void)hipStreamDestroy(r.stream);
     r.stream = nullptr;
     r.up = false;
     return STSTHIP_OK;
@@ -393,12 +393,12 @@ int ststhip_pool_trim(void) {
     Runtime &r = rt();
     std::lock_guard<std::mutex> guard(r.lock);
     if (r.up)
-        hipStreamSynchronize(r.stream);
+        (void)hipStreamSynchronize(r.stream);
     for (auto &kv : r.free_blocks)
-        hipFree(kv.second);
+        (void)hipFree(kv.second);
     r.free_blocks.clear();
     for (auto &kv : r.free_host_blocks)
-        hipHostFree(kv.second);
+        (void)hipHostFree(kv.second);
     r.free_host_blocks.clear();
     r.cached_host_bytes = 0;
     return STSTHIP_OK;
@@ -747,6 +747,11 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
     std::uint64_t n_launches = 0;
     int rc = STSTHIP_OK;
     void *scratch[16] = {nullptr};
+    // events and stream waits carry the ordering between strips: a failure there must fail the run
+    auto ordered = [&](hipError_t err, const char *what) {
+        if (err != hipSuccess && rc == STSTHIP_OK)
+            rc = hip_fail(err, what);
+    };
 
     // how many virtual strips: only worth it for grids with many rows per strip
     const std::uint64_t g_max = std::uint64_t(desc->max_generations) * desc->halo_depth_per_generation;
@@ -763,7 +768,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
 
         auto new_event = [&]() {
             hipEvent_t e = nullptr;
-            hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            ordered(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
             sync_events.push_back(e);
             return e;
         };
@@ -781,10 +786,10 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             }
             if (strips > 1) {
                 hipEvent_t begin = new_event();
-                hipEventRecord(begin, s);
+                ordered(hipEventRecord(begin, s), "hipEventRecord");
                 for (int v = 1; v < strips; v++) {
                     lane[v] = pool[v - 1];
-                    hipStreamWaitEvent(lane[v], begin, 0);
+                    ordered(hipStreamWaitEvent(lane[v], begin, 0), "hipStreamWaitEvent");
                 }
             } else {
                 lane.assign(1, s);
@@ -807,9 +812,9 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             const std::uint64_t g = std::uint64_t(depths[pass]) * desc->halo_depth_per_generation;
             hipEvent_t t0 = nullptr, t1 = nullptr;
             if (profiling) {
-                hipEventCreate(&t0);
-                hipEventCreate(&t1);
-                hipEventRecord(t0, s);
+                ordered(hipEventCreate(&t0), "hipEventCreate");
+                ordered(hipEventCreate(&t1), "hipEventCreate");
+                ordered(hipEventRecord(t0, s), "hipEventRecord");
             }
             std::vector<hipEvent_t> bands_now(strips, nullptr);
             for (int v = 0; v < strips && rc == STSTHIP_OK; v++) {
@@ -822,9 +827,9 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                 // bands read the neighbours' bands of the previous pass (and will overwrite rows
                 // the neighbours' previous bands read): wait for them
                 if (v > 0 && bands_done[v - 1])
-                    hipStreamWaitEvent(lane[v], bands_done[v - 1], 0);
+                    ordered(hipStreamWaitEvent(lane[v], bands_done[v - 1], 0), "hipStreamWaitEvent");
                 if (v + 1 < strips && bands_done[v + 1])
-                    hipStreamWaitEvent(lane[v], bands_done[v + 1], 0);
+                    ordered(hipStreamWaitEvent(lane[v], bands_done[v + 1], 0), "hipStreamWaitEvent");
                 const std::uint64_t top_end = (v > 0) ? std::min(a + g, b) : a;
                 const std::uint64_t bot_begin = (v + 1 < strips) ? std::max(b - std::min(g, b - a), top_end) : b;
                 if (top_end > a) {
@@ -836,7 +841,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                     n_launches++;
                 }
                 bands_now[v] = new_event();
-                hipEventRecord(bands_now[v], lane[v]);
+                ordered(hipEventRecord(bands_now[v], lane[v]), "hipEventRecord");
                 if (rc == STSTHIP_OK && top_end < bot_begin) {
                     rc = sweep(ctx, dom, from, to, top_end, bot_begin, iteration, depths[pass], lane[v]);
                     n_launches++;
@@ -844,7 +849,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             }
             bands_done.swap(bands_now);
             if (profiling) {
-                hipEventRecord(t1, s);
+                ordered(hipEventRecord(t1, s), "hipEventRecord");
                 timed.emplace_back(t0, t1);
             }
             from = const_cast<const void *const *>(to);
@@ -854,8 +859,8 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         // join: the caller's stream continues after every strip has finished
         for (int v = 1; v < strips; v++) {
             hipEvent_t done = new_event();
-            hipEventRecord(done, lane[v]);
-            hipStreamWaitEvent(s, done, 0);
+            ordered(hipEventRecord(done, lane[v]), "hipEventRecord");
+            ordered(hipStreamWaitEvent(s, done, 0), "hipStreamWaitEvent");
         }
     }
     if (rc == STSTHIP_OK && (blocking || profiling)) {
@@ -871,11 +876,11 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         float ms = 0.0f;
         if (rc == STSTHIP_OK && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess)
             kernel_s += double(ms) * 1e-3;
-        hipEventDestroy(ev.first);
-        hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
     }
     for (hipEvent_t e : sync_events)
-        hipEventDestroy(e);
+        (void)hipEventDestroy(e);
     if (info) {
         std::chrono::duration<double> elapsed = std::chrono::high_resolution_clock::now() - started;
         info->walltime_s = elapsed.count();
