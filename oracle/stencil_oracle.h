@@ -13,7 +13,9 @@
  * The numerical results of Jacobi/HotSpot/FDTD are pinned by NO test of the
  * reference ("parity unpinned" at application level); the
  * known answers recorded in SURVEY.md section 8c (reference cpu backend run by
- * the survey) are the only numerical anchors and are checked in
+ * the survey) are the numerical anchors for Jacobi, HotSpot and Conway, and
+ * the frames written by the reference's unchanged examples/fdtd sources
+ * (tests/golden/fdtd, six printed digits) anchor FDTD; all are checked in
  * tests/test_oracle_golden.py.  The reference itself needs a SYCL
  * implementation that this image lacks, so it is unbuildable here; only the
  * third-party Rodinia file examples/hotspot/hotspot_openmp.cpp builds from its

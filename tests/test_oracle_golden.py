@@ -130,3 +130,46 @@ def test_hotspot_against_rodinia_openmp(oracle, tmp_path):
     ref = np.loadtxt(out_file, dtype=np.float64)[:, 1].reshape(64, 64)
     out = oracle.hotspot(oracle.hotspot_params(64, 64), load_hotspot(oracle), 100)["temp"]
     assert np.abs(out.astype(np.float64) - ref).max() <= 2 * KNOWN["hotspot_64"]["rodinia_openmp_max_abs_diff"]
+
+
+def test_fdtd_oracle_against_unchanged_reference_functor(oracle):
+    """Pins the oracle's FDTD restatement (transition function, TDV, and the example's set-up
+    arithmetic restated in tests/fdtd_harness.py): tests/golden/fdtd/*.csv were written by the
+    reference's unchanged examples/fdtd sources (tests/golden/make_fdtd_golden.py says how).  The frames
+    carry 6 significant digits (default ostream formatting, fdtd.cpp:118-161), so agreement is required
+    to half a unit of the sixth digit; 1029 generations x 2 sub-iterations, three update calls with an
+    iteration offset, source cut-off and detection window inside the run, a lossy outer ring."""
+    import json
+
+    from fdtd_harness import Experiment, load_csv
+
+    here = os.path.join(GOLDEN, "fdtd")
+    ex = Experiment(json.load(open(os.path.join(here, "experiment.json"))))
+    stdout = open(os.path.join(here, "stdout.txt")).read()
+    assert f"grid w/h          = {ex.grid_width()} cells" in stdout
+    assert f"n. timesteps      = {ex.n_timesteps()}" in stdout
+    assert f"n. snap timesteps = {ex.n_snap_timesteps()}" in stdout
+    assert f"dt                = {float(ex.dt()):.6g} s/iteration" in stdout
+
+    params = oracle.FdtdParams()
+    for k, v in ex.kernel_constants().items():
+        setattr(params, k, v if isinstance(v, int) else float(v))
+    cells = ex.initial_grid(oracle.FDTD_CELL)
+    assert len(np.unique(cells["cb"])) == 3  # two rings and the metal around them
+
+    def agrees(got, path):
+        want = load_csv(path)
+        assert want.shape == got.shape
+        # a printed value is the nearest 6-significant-digit decimal of the float
+        tol = 0.5000001 * 10.0 ** (np.floor(np.log10(np.maximum(np.abs(want), 1e-300))) - 5)
+        worst = np.max(np.abs(got.astype(np.float64) - want) / tol)
+        assert worst <= 1.0, (path, worst)
+
+    calls = ex.update_calls()
+    assert [c[2] for c in calls] == [343, 686, 1029]
+    for offset, n, label in calls:
+        cells = oracle.fdtd(params, cells, n, iteration_offset=offset, n_threads=4)
+        assert np.abs(cells["hz"]).max() > 0
+        agrees(cells["hz"], os.path.join(here, f"hz.{label}.csv"))
+    assert np.abs(cells["hz_sum"]).max() > 0
+    agrees(cells["hz_sum"], os.path.join(here, f"hz_sum.{ex.n_timesteps()}.csv"))

@@ -181,6 +181,37 @@ def test_fdtd_bit_exact(gpu, oracle, shape, split):
     assert np.abs(want["hz_sum"]).max() > 0 and np.abs(want["hz"]).max() > 0
 
 
+@pytest.mark.parametrize("split", [True, False], ids=["soa", "aos"])
+def test_fdtd_reference_functor_frames_on_gpu(gpu, oracle, split):
+    """The frames the reference's unchanged examples/fdtd sources wrote (tests/golden/fdtd, see
+    make_fdtd_golden.py) against the HIP kernels through the C ABI: equal to the oracle bit for bit, and
+    equal to the frames to the six digits they carry; three update calls with an iteration offset."""
+    import json
+
+    from fdtd_harness import Experiment, load_csv
+    from stencilstream_amd import capi, update as U
+
+    here = os.path.join(os.path.dirname(__file__), "golden", "fdtd")
+    ex = Experiment(json.load(open(os.path.join(here, "experiment.json"))))
+    po, pc = oracle.FdtdParams(), capi.FdtdParams()
+    for k, v in ex.kernel_constants().items():
+        setattr(po, k, v if isinstance(v, int) else float(v))
+        setattr(pc, k, v if isinstance(v, int) else float(v))
+    cells = ex.initial_grid(oracle.FDTD_CELL)
+    want = cells
+    halo = np.zeros((), dtype=U.FDTD_CELL)
+    for offset, n, label in ex.update_calls():
+        cells = run_hip(U.fdtd(pc, split), cells, n, halo=halo, offset=offset)
+        want = oracle.fdtd(po, want, n, iteration_offset=offset, n_threads=8)
+        assert np.array_equal(bits(cells), bits(want)), label
+        frame = load_csv(os.path.join(here, f"hz.{label}.csv"))
+        tol = 0.5000001 * 10.0 ** (np.floor(np.log10(np.maximum(np.abs(frame), 1e-300))) - 5)
+        assert np.all(np.abs(cells["hz"].astype(np.float64) - frame) <= tol), label
+    frame = load_csv(os.path.join(here, f"hz_sum.{ex.n_timesteps()}.csv"))
+    tol = 0.5000001 * 10.0 ** (np.floor(np.log10(np.maximum(np.abs(frame), 1e-300))) - 5)
+    assert np.all(np.abs(cells["hz_sum"].astype(np.float64) - frame) <= tol)
+
+
 def test_sweep_row_ranges_compose(gpu, oracle):
     """ststhip_app_sweep on row bands with ghost rows (the multi-GPU building block): three strips
     with emulated ghost exchange equal the whole-grid result."""
