@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <string>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -251,6 +252,14 @@ struct SweepGeometry {
     std::int32_t out_begin, out_end;    // global rows to produce
     std::int32_t chunk_rows;            // rows of output per wave
     std::uint32_t n_strips, n_chunks;   // wave grid
+    // The last waves of the grid (dispatched last) take shorter chunks, so that the ragged end of a
+    // launch -- SIMDs left with one or two waves -- is short.  Tier t covers chunks
+    // [tier_first[t], tier_first[t+1]) with tier_rows[t] rows each; tier 0 starts at out_begin.
+    static constexpr int max_tiers = 4;
+    std::uint32_t n_tiers;
+    std::uint32_t tier_first[max_tiers + 1];
+    std::int32_t tier_rows[max_tiers];
+    std::int32_t tier_begin[max_tiers]; // first output row of the tier
     std::uint64_t pitch;                // elements between rows
     std::uint64_t iteration;            // generation index of the first level
     std::uint32_t xcd_remap;            // 1: give every XCD a contiguous range of the wave grid
@@ -461,8 +470,14 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
             return;
         const int strip = int(wave % g.n_strips);
         const int chunk = int(wave / g.n_strips);
-        const int ya = g.out_begin + chunk * g.chunk_rows;
-        const int yb = ya + g.chunk_rows < g.out_end ? ya + g.chunk_rows : g.out_end;
+        int tier = 0;
+#pragma unroll
+        for (int t = 1; t < SweepGeometry::max_tiers; t++)
+            if (t < int(g.n_tiers) && unsigned(chunk) >= g.tier_first[t])
+                tier = t;
+        const int ya = g.tier_begin[tier] + (chunk - int(g.tier_first[tier])) * g.tier_rows[tier];
+        int yb = ya + g.tier_rows[tier];
+        yb = yb < g.out_end ? yb : g.out_end;
 
         if constexpr (INTERIOR_VARIANT) {
             const int xw0 = strip * OW - GX;
@@ -525,6 +540,51 @@ inline int pick_chunk_rows(int out_rows, unsigned n_strips, int halo_rows, int r
     return int((out_rows + chunks - 1) / chunks);
 }
 
+// Chunk lengths of a launch.  All chunks have g.chunk_rows rows, except that the tail of the wave grid is
+// cut finer: STSTHIP_TAPER = "permille:split[,permille:split...]" makes the last `permille` of the rows
+// chunks of chunk_rows/split rows (later entries refine the end further; they must shrink).
+inline void plan_tiers(SweepGeometry &g, int out_rows) {
+    g.n_tiers = 1;
+    g.tier_first[0] = 0;
+    g.tier_rows[0] = g.chunk_rows;
+    g.tier_begin[0] = g.out_begin;
+    // Default (profiles/r01_tune_taper.txt): the last 12 % of the rows in quarter-length chunks when the
+    // launch has the chip to itself (+7 % for a full-grid Jacobi launch, +2..4 % HotSpot / FDTD); launches
+    // that run side by side already fill each other's ends and lose 1-6 % with shorter chunks.
+    const char *spec = std::getenv("STSTHIP_TAPER");
+    std::string text = spec ? spec : (ststhip_launch_concurrency() == 1 ? "120:4" : "150:2");
+    int done_rows = 0; // rows covered by the tiers closed so far
+    unsigned done_chunks = 0;
+    std::size_t at = 0;
+    int previous_start = 0;
+    while (at < text.size() && g.n_tiers < unsigned(SweepGeometry::max_tiers)) {
+        const int permille = std::atoi(text.c_str() + at);
+        const std::size_t colon = text.find(':', at);
+        if (colon == std::string::npos)
+            break;
+        const int split = std::atoi(text.c_str() + colon + 1);
+        const std::size_t comma = text.find(',', colon);
+        at = comma == std::string::npos ? text.size() : comma + 1;
+        const int rows = (g.chunk_rows + std::max(split, 1) - 1) / std::max(split, 1);
+        // the tier starts at a chunk boundary of the tier before it
+        const int current = g.tier_rows[g.n_tiers - 1];
+        int start = out_rows - int(std::int64_t(out_rows) * std::clamp(permille, 0, 1000) / 1000);
+        start = done_rows + (std::max(start - done_rows, 0) / current) * current;
+        if (split <= 1 || rows < 4 || rows >= current || start <= previous_start || start >= out_rows)
+            continue;
+        done_chunks += unsigned((start - done_rows) / current);
+        done_rows = start;
+        previous_start = start;
+        g.tier_first[g.n_tiers] = done_chunks;
+        g.tier_rows[g.n_tiers] = rows;
+        g.tier_begin[g.n_tiers] = g.out_begin + start;
+        g.n_tiers++;
+    }
+    const int last = g.tier_rows[g.n_tiers - 1];
+    g.n_chunks = done_chunks + unsigned((out_rows - done_rows + last - 1) / last);
+    g.tier_first[g.n_tiers] = g.n_chunks;
+}
+
 // One kernel launch = T generations over global rows [out_begin, out_end).
 template <typename F, bool SOA, int T>
 void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDependentValue const *tdv,
@@ -557,6 +617,7 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), g.n_strips, SW::G, resident_blocks,
                                    int(waves_per_block));
     g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
+    plan_tiers(g, int(out_end - out_begin));
     g.pitch = dom.pitch;
     g.iteration = iteration;
     // measured (profiles/r01_xcd_remap.txt): 4 % fewer HBM reads, but no gain in time for these
