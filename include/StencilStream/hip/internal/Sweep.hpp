@@ -263,6 +263,7 @@ struct SweepGeometry {
     std::uint64_t pitch;                // elements between rows
     std::uint64_t iteration;            // generation index of the first level
     std::uint32_t xcd_remap;            // 1: give every XCD a contiguous range of the wave grid
+    std::uint32_t last_chunk_early;     // 1: the last row chunk is dispatched second instead of last
 };
 
 template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> struct Sweep {
@@ -469,7 +470,11 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
         if (wave >= g.n_strips * g.n_chunks)
             return;
         const int strip = int(wave % g.n_strips);
-        const int chunk = int(wave / g.n_strips);
+        // The bottom chunk of a launch that reaches the grid's last rows runs the slower edge code; in
+        // dispatch order it would come last and stretch the end of the launch, so it is moved to the front.
+        int chunk = int(wave / g.n_strips);
+        if (g.last_chunk_early && g.n_chunks >= 3)
+            chunk = chunk == 0 ? 0 : (chunk == 1 ? int(g.n_chunks) - 1 : chunk - 1);
         int tier = 0;
 #pragma unroll
         for (int t = 1; t < SweepGeometry::max_tiers; t++)
@@ -608,6 +613,7 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
                                                     dom.row_origin + std::int64_t(dom.local_rows)));
     g.out_begin = std::int32_t(out_begin);
     g.out_end = std::int32_t(out_end);
+    // 4 waves per workgroup: 2 or 1 are 1-3 % slower (profiles/r01_tune_taper.txt, last section)
     constexpr unsigned waves_per_block = 4;
     const void *kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd>);
     static int resident_blocks = 0; // per kernel instantiation
@@ -623,6 +629,7 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     // measured (profiles/r01_xcd_remap.txt): 4 % fewer HBM reads, but no gain in time for these
     // VALU-bound kernels, so the remap is off unless asked for
     g.xcd_remap = env_int("STSTHIP_XCD_REMAP", 0) ? 1u : 0u;
+    g.last_chunk_early = (out_end + SW::G > dom.global_height && env_int("STSTHIP_LAST_CHUNK_EARLY", 1)) ? 1u : 0u;
 
     // transition functions need not be default-constructible: build the argument block in one go
     typename SW::Args args = [&]<std::size_t... Is>(std::index_sequence<Is...>) {
