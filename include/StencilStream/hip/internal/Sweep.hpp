@@ -207,6 +207,9 @@ template <typename Cell, bool SOA> constexpr int cell_words() {
 //   prefetch_rows (P)    rows loaded ahead; must be a multiple of 2*radius
 //   interior_variant     also build the check-free code path for waves away from the grid edge
 //   min_waves_per_simd   occupancy the register allocator must allow (second __launch_bounds__ argument)
+//   trapezoid_fill       (optional member) skip the levels that are not due yet while a wave's pipeline fills;
+//                        default: cells of up to four words per generation (measured: Jacobi +3 %, HotSpot
+//                        +5 %, Conway +4 %, FDTD -2..-8 %: profiles/r01_ab_trapezoid_fill.txt)
 template <typename F, bool SOA> struct SweepTuning {
   private:
     static constexpr int R = int(F::stencil_radius);
@@ -265,6 +268,13 @@ struct SweepGeometry {
     std::uint32_t xcd_remap;            // 1: give every XCD a contiguous range of the wave grid
     std::uint32_t last_chunk_early;     // 1: the last row chunk is dispatched second instead of last
 };
+
+template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })
+        return SweepTuning<F, SOA>::trapezoid_fill;
+    else
+        return cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 4;
+}
 
 template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> struct Sweep {
     using Cell = typename F::Cell;
@@ -351,9 +361,14 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
 
         static_for<0, P>([&](auto u) __attribute__((always_inline)) { load_row(ystart + u, pre[u]); });
 
+        // One input row through the pipeline.  While the pipeline fills (FILLING: the first 2G rows of the
+        // wave) level l only has to produce rows from input row 2*l*R of the wave on -- earlier outputs
+        // cannot reach a stored row -- so the deeper levels are skipped by wave-uniform branches: a
+        // trapezoid of level-steps instead of a parallelogram, G*(S+1) fewer of them per wave.
         const int n_rows_in = yb - ya + 2 * G;
-        for (int it = 0; it < n_rows_in; it += P) {
-            static_for<0, P>([&](auto u) __attribute__((always_inline)) {
+        auto row_step = [&](auto u, const int it, auto filling) __attribute__((always_inline)) {
+                constexpr bool FILLING = decltype(filling)::value;
+                const int step = it + u; // index of the input row inside the wave
                 const int y = ystart + it + u;
                 Cell cur[K];
 #pragma unroll
@@ -369,9 +384,22 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                             cur[k] = a.halo;
                 }
 
+                bool live = true; // FILLING: the levels up to here are due at this row
                 static_for<0, S>([&](auto lc) __attribute__((always_inline)) {
                     constexpr int level = lc + 1;           // level being computed
                     constexpr int oldest = u % NWIN;        // window slot holding the oldest row
+                    if constexpr (FILLING) {
+                        if (!live)
+                            return;
+                        if (step < 2 * level * R) {
+                            // not due yet, but its window takes the row the level before it just emitted
+#pragma unroll
+                            for (int k = 0; k < K; k++)
+                                win[lc][oldest][k] = cur[k];
+                            live = false;
+                            return;
+                        }
+                    }
                     const int j = y - level * R;            // global row this level emits now
                     const std::size_t iteration = g.iteration + std::size_t((level - 1) / NS);
                     const std::size_t subiteration = std::size_t((level - 1) % NS);
@@ -436,7 +464,7 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                 });
 
                 const int j = y - G; // row leaving the last level
-                if (j >= ya && j < yb && lane_stores) {
+                if ((!FILLING || live) && j >= ya && j < yb && lane_stores) {
                     const std::size_t first =
                         std::size_t(j - g.row_origin) * g.pitch + std::size_t(std::int64_t(x0));
                     if (!EDGE || vec_in) {
@@ -448,8 +476,16 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                                 a.dst.store_one(first + k, cur[k]);
                     }
                 }
-            });
+        };
+
+        // Waves at the grid edge are few: they keep one loop (every level at every row) and small code.
+        int it = 0;
+        if constexpr (!EDGE && trapezoid_fill_for<F, SOA>()) {
+            for (; it < 2 * G && it < n_rows_in; it += P)
+                static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, it, std::true_type{}); });
         }
+        for (; it < n_rows_in; it += P)
+            static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, it, std::false_type{}); });
     }
 
     STST_DEVICE static void entry(Args const &a) {
