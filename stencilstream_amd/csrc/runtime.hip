@@ -975,6 +975,23 @@ int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cel
             e = uniform.middle; // same geometry for all four variants
         }
     }
+    // Game of Life with a dead halo on a grid whose width and pitch are multiples of four cells: the same
+    // rule on 32-bit words of four cells (apps/conway.hpp, ConwayPacked), swept as a grid of words
+    ststhip_domain words;
+    bool use_packed = false;
+    if (std::strcmp(app, "conway") == 0 && n_iterations > 0 && dom->global_width > 0 &&
+        dom->global_width % 4 == 0 && dom->pitch % 4 == 0 && *static_cast<const unsigned char *>(halo_cell) == 0 &&
+        reinterpret_cast<std::uintptr_t>(src[0]) % 4 == 0 && reinterpret_cast<std::uintptr_t>(dst[0]) % 4 == 0 &&
+        stencil::hip::internal::env_int("STSTHIP_CONWAY_FASTPATH", 1)) {
+        if (const AppEntry *packed = find_app("conway_packed")) {
+            e = packed;
+            words = *dom;
+            words.global_width = dom->global_width / 4;
+            words.pitch = dom->pitch / 4;
+            dom = &words;
+            use_packed = true;
+        }
+    }
     ststhip_sweep_desc desc;
     std::memset(&desc, 0, sizeof desc);
     desc.n_planes = e->info.n_planes;
@@ -986,9 +1003,13 @@ int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cel
     if (use_uniform)
         return ststhip_run_passes(uniform_jacobi_trampoline, &uniform, &desc, dom, src, dst, iteration_offset,
                                   n_iterations, blocking, profiling, stream, info);
-    AppCall call{e, tf_params, halo_cell};
-    return ststhip_run_passes(app_sweep_trampoline, &call, &desc, dom, src, dst, iteration_offset,
-                              n_iterations, blocking, profiling, stream, info);
+    const std::uint32_t dead_word = 0;
+    AppCall call{e, tf_params, use_packed ? static_cast<const void *>(&dead_word) : halo_cell};
+    const int rc = ststhip_run_passes(app_sweep_trampoline, &call, &desc, dom, src, dst, iteration_offset,
+                                      n_iterations, blocking, profiling, stream, info);
+    if (use_packed && info)
+        info->n_processed_cells *= 4; // counted in words by the pass driver
+    return rc;
 }
 
 // ------------------------------------------------------------------ multi-GPU

@@ -84,6 +84,29 @@ def test_conway_bit_exact(gpu, oracle, shape):
         assert np.array_equal(run_hip(U.conway(), grid, n), oracle.conway(grid, n, n_threads=8)), f"n={n}"
 
 
+@pytest.mark.parametrize("shape", [(1, 4), (5, 8), (3, 252), (257, 1028), (1000, 772), (2048, 4096)], ids=str)
+def test_conway_word_form_equals_byte_form(gpu, oracle, monkeypatch, shape):
+    """Widths that are multiples of four run the rule on 32-bit words of four cells (ConwayPacked); the
+    byte-per-lane kernel and the oracle must agree with it bit for bit, at every launch depth."""
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(0xC0FFEE ^ shape[1])
+    grid = (rng.random(shape) < 0.4).astype(np.uint8)
+    for n in (1, 3, 8, 21, 50):
+        monkeypatch.setenv("STSTHIP_CONWAY_FASTPATH", "1")
+        words = run_hip(U.conway(), grid, n)
+        monkeypatch.setenv("STSTHIP_CONWAY_FASTPATH", "0")
+        cells = run_hip(U.conway(), grid, n)
+        want = oracle.conway(grid, n, n_threads=8)
+        assert np.array_equal(words, want), f"word form, n={n}"
+        assert np.array_equal(cells, want), f"byte form, n={n}"
+    # a live halo is outside the word form's preconditions: same result with the switch on and off
+    monkeypatch.setenv("STSTHIP_CONWAY_FASTPATH", "1")
+    live = run_hip(U.conway(), grid, 9, halo=np.uint8(1))
+    monkeypatch.setenv("STSTHIP_CONWAY_FASTPATH", "0")
+    assert np.array_equal(live, run_hip(U.conway(), grid, 9, halo=np.uint8(1)))
+
+
 def test_conway_gosper_gun_known_answer(gpu):
     """BASELINE config 0 input: the reference's 64x64 start pattern, md5 of the printed grid."""
     from stencilstream_amd import update as U

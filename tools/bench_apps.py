@@ -125,10 +125,11 @@ def main():
                                     detect_iteration=0, source_radius_squared=100.0, source_r=H / 2, source_c=W / 2,
                                     source_distance_bound=100.0 - 2 * (H / 2) ** 2, double_center_rc=float(H))
             else:
-                H, W, gens, p, fill = 16384, 16384, 192, capi.NoParams(), None
+                # packed Game of Life: a 16384^2 grid of cells = 16384 x 4096 words of four cells
+                H, W, gens, p, fill = 16384, 4096, 192, capi.NoParams(), None
             halo = bytes(meta.cell_size)
             if fill is None:
-                pa = [(torch.rand(H, W, device=dev) < 0.35).to(torch.uint8)]
+                pa = [(torch.rand(H, 4 * W, device=dev) < 0.35).to(torch.uint8).view(torch.int32)]
             elif meta.n_planes == 1:
                 cells = torch.empty(H, W, len(fill), device=dev)
                 for i, v in enumerate(fill):
@@ -145,7 +146,10 @@ def main():
         info = capi.app_info(app)
         best, launches = run(app, p, halo, pa, pb, H, W, gens, stream)
         bytes_per_update = 2 * info.cell_size * info.n_subiterations
-        gcells = H * W * gens / best / 1e9
+        if name.startswith("x_cw_"):
+            bytes_per_update = 2  # one byte per cell of the game, four cells per word
+        cells_per_elem = 4 if name.startswith("x_cw_") else 1
+        gcells = H * W * cells_per_elem * gens / best / 1e9
         line = {"app": app, "grid": [H, W], "generations": gens, "Gcell_updates_per_s": round(gcells, 1),
                 "ms_per_launch": round(best / launches * 1e3, 4), "generations_per_launch": gens / launches,
                 "algorithmic_bytes_per_cell_update": bytes_per_update,
