@@ -56,13 +56,25 @@ def init_grid_device(torch, rows, cols, row0, total_rows, device):
     return inside.to(torch.float32).contiguous()
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup's CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, cores)
+
+
 def cpu_baseline(size, generations):
     """The oracle (a port of the reference's cpu backend) on the host cores, bounded sample."""
     import numpy as np
 
     from oracle import oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     grid = O.jacobi_init(size, size)
     O.jacobi("Jacobi5General", COEF, grid[:64, :64].copy(), 1, n_threads=cores)  # warm the pool
     t0 = time.perf_counter()
