@@ -41,7 +41,7 @@ def test_registry_describes_the_apps(built_lib):
     for name in ("jacobi1general", "jacobi2constant", "jacobi3constant", "jacobi4constant",
                  "jacobi5constant", "jacobi4general", "jacobi5general", "jacobi9general", "hotspot",
                  "hotspot_aos", "hotspot_f64", "hotspot_f64_aos", "jacobi5uniform", "jacobi5uniform_first",
-                 "jacobi5uniform_last", "jacobi5uniform_only", "jacobi5general_fma", "conway", "selfcheck1", "selfcheck1_soa", "selfcheck2", "fdtd_coef",
+                 "jacobi5uniform_last", "jacobi5uniform_only", "jacobi5general_fma", "conway", "conway_packed", "selfcheck1", "selfcheck1_soa", "selfcheck2", "fdtd_coef",
                  "fdtd_coef_aos"):
         assert name in apps
     j = capi.app_info("jacobi5general")
