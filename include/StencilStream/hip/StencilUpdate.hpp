@@ -11,7 +11,7 @@
 // the walltime covers scratch allocation, scatter, sweeps, gather and -- if `blocking` -- the final
 // synchronisation (:129-139); n_processed_cells does not count sub-iterations (:140-141);
 // split_cell_structure = true scatters the AoS cells into per-field planes, sweeps on those and
-// gathers back (:294-438).
+// gathers back (:294-438) -- for cells thin enough that planes pay off (SplitCellPolicy below).
 //
 // What differs by design: instead of one kernel per (iteration, sub-iteration), one kernel
 // advances up to SweepTuning<F>::max_generations generations (hip/internal/Sweep.hpp).
@@ -27,10 +27,32 @@
 namespace stencil {
 namespace hip {
 
+// Which layout the sweeps of StencilUpdate<F, true> run on.  The reference's GPU backend needs per-field
+// planes for coalescing because one work-item loads one cell (cuda/StencilUpdate.hpp:346-396).  Here a lane
+// loads whole cells with one vector access, so for fat cells the AoS sweep is the faster one (FDTD, 8 words:
+// 342 vs 270 Gcell/s at 4608^2, profiles/r01_tune_shapes_apps_2.txt) and needs no scatter / gather passes;
+// thin cells keep their planes (HotSpot, 2 words: 1632 vs 1583).  Results are identical either way, so
+// split_cell_structure = true is honoured as a request for planes only where planes pay off.  Specialise to
+// decide differently for a transition function.
+template <typename F> struct SplitCellPolicy {
+    static constexpr bool sweep_on_planes = [] {
+        if constexpr (internal::SplittableCell<typename F::Cell>)
+            return internal::cell_words<typename F::Cell, true>() < 4;
+        else
+            return true; // PlaneSet reports the missing Cell::fields
+    }();
+};
+
 template <concepts::TransitionFunction F, bool split_cell_structure = false> class StencilUpdate {
     using Cell = typename F::Cell;
     using TDV = typename F::TimeDependentValue;
-    using Planes = internal::PlaneSet<Cell, split_cell_structure>;
+    static constexpr bool on_planes = [] {
+        if constexpr (split_cell_structure)
+            return SplitCellPolicy<F>::sweep_on_planes;
+        else
+            return false;
+    }();
+    using Planes = internal::PlaneSet<Cell, on_planes>;
 
   public:
     using GridImpl = Grid<Cell>;
@@ -91,7 +113,7 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
                 from.plane[f] = const_cast<void *>(src[f]);
                 to.plane[f] = dst[f];
             }
-            internal::dispatch_sweep<F, split_cell_structure>(
+            internal::dispatch_sweep<F, on_planes>(
                 int(depth), self->params.transition_function, self->params.halo_value, tdv.data(),
                 *dom, from, to, out_begin, out_end, iteration, stream);
             return STSTHIP_OK;
@@ -108,11 +130,11 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
                     ststhip_stream stream) {
         ststhip_sweep_desc desc = {};
         desc.n_planes = Planes::n_planes;
-        desc.max_generations = SweepTuning<F, split_cell_structure>::max_generations;
+        desc.max_generations = SweepTuning<F, on_planes>::max_generations;
         desc.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
-        using Tuning = SweepTuning<F, split_cell_structure>;
+        using Tuning = SweepTuning<F, on_planes>;
         desc.strip_width = std::uint32_t(
-            internal::Sweep<F, split_cell_structure, Tuning::max_generations, Tuning::cells_per_lane,
+            internal::Sweep<F, on_planes, Tuning::max_generations, Tuning::cells_per_lane,
                             Tuning::prefetch_rows, Tuning::interior_variant>::OW);
         for (int f = 0; f < Planes::n_planes; f++)
             desc.plane_elem_size[f] = Planes::elem_size(f);
@@ -126,9 +148,11 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
     }
 
     GridImpl simulate(GridImpl &source_grid, ststhip_stream stream)
-        requires(!split_cell_structure)
+        requires(!on_planes)
     {
-        if (params.n_iterations == 0)
+        // the reference's split path always returns a fresh grid (cuda/StencilUpdate.hpp:285,440), its AoS
+        // path a handle onto the source when there is nothing to do (:206,275)
+        if (params.n_iterations == 0 && !split_cell_structure)
             return source_grid;
         ststhip_domain dom = domain_of(source_grid);
         GridImpl result = source_grid.make_similar();
@@ -140,7 +164,7 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
     }
 
     GridImpl simulate(GridImpl &source_grid, ststhip_stream stream)
-        requires(split_cell_structure)
+        requires(on_planes)
     {
         ststhip_domain dom = domain_of(source_grid);
         const std::size_t n_cells = source_grid.get_grid_height() * source_grid.get_grid_width();

@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <initializer_list>
 #include <string>
 #include <tuple>
 #include <type_traits>
@@ -203,7 +204,7 @@ template <typename Cell, bool SOA> constexpr int cell_words() {
 
 // Shape of the wave pipeline for a transition function.  Specialise for a concrete F to override:
 //   cells_per_lane (K)   adjacent cells per lane and row (vector width of the HBM accesses)
-//   max_generations (T)  deepest temporal blocking compiled (powers of two up to it are built)
+//   max_generations (T)  deepest temporal blocking compiled (it and its repeated halvings are built)
 //   prefetch_rows (P)    rows loaded ahead; must be a multiple of 2*radius
 //   interior_variant     also build the check-free code path for waves away from the grid edge
 //   min_waves_per_simd   occupancy the register allocator must allow (second __launch_bounds__ argument)
@@ -223,16 +224,29 @@ template <typename F, bool SOA> struct SweepTuning {
         int k = (W == 1) ? 4 : ((W == 2 && !SOA) ? 2 : 1);
         return std::max(k, internal::ceil_pow2(R));
     }
-    // deepest power of two up to 8 generations whose window stays within 128 words per lane
-    static constexpr int pick_t(int k) {
-        int t = 8;
-        while (t > 1 && (t * NS * 2 * R * k * W > 128 || 64 * k <= 2 * internal::round_up(R * t * NS, k)))
-            t /= 2;
-        return t;
+    // Deepest power of two up to 8 generations whose window stays within 128 words per lane -- and 6 for
+    // functions with sub-iterations: they touch only part of the cell (and of the neighbourhood) per sub-step,
+    // so part of the nominal window is dead after inlining.  Measured on FDTD (8 words, 2 sub-iterations): the
+    // best depth is 6, a nominal 192 words (profiles/r01_tune_shapes_apps.txt: T = 4: 270, 6: 347, 7: 234
+    // Gcell/s; the unchanged example: 1.96 -> 1.46 s, profiles/r01_ab_examples.txt).  Counting two thirds of
+    // the nominal window at depth 6 reproduces that; it is only trusted for up to 8 words per lane, and a
+    // window that fits as it is keeps the powers of two (FDTD with the LUT resolver, 5 words: T = 4 beats 6 and 8).
+    static constexpr int nominal_window(int t, int k) { return t * NS * 2 * R * k * W; }
+    static constexpr bool geometry_ok(int t, int k) { return 64 * k > 2 * internal::round_up(R * t * NS, k); }
+    static constexpr bool relaxed(int t, int k) {
+        return t == 6 && NS >= 2 && k * W <= 8 && nominal_window(t, k) > 128 && nominal_window(t, k) * 2 / 3 <= 128 &&
+               geometry_ok(t, k);
     }
-    static constexpr int pick_p() {
+    static constexpr int pick_t(int k) {
+        for (int t : {8, 6, 4, 2})
+            if (t == 6 ? relaxed(t, k) : (nominal_window(t, k) <= 128 && geometry_ok(t, k)))
+                return t;
+        return 1;
+    }
+    // rows in flight: at least four, except where the window was admitted on the relaxed count
+    static constexpr int pick_p(int t, int k) {
         int p = 2 * R;
-        while (p < 4)
+        while (p < 4 && !relaxed(t, k))
             p += 2 * R;
         return p;
     }
@@ -240,7 +254,7 @@ template <typename F, bool SOA> struct SweepTuning {
   public:
     static constexpr int cells_per_lane = pick_k();
     static constexpr int max_generations = pick_t(cells_per_lane);
-    static constexpr int prefetch_rows = pick_p();
+    static constexpr int prefetch_rows = pick_p(max_generations, cells_per_lane);
     static constexpr bool interior_variant = (W * NS <= 16);
     static constexpr int min_waves_per_simd = 1;
 };

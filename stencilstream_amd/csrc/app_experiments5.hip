@@ -11,3 +11,23 @@ STSTHIP_REGISTER_APP("x_fd_aos_k2t4p2", G1, false);
 STSTHIP_REGISTER_APP("x_fd_soa_k2t4p2", G1, true);
 STSTHIP_REGISTER_APP("x_fd_aos_k2t3p2", G2, false);
 STSTHIP_REGISTER_APP("x_fd_aos_k2t6p2", G3, false);
+
+// HotSpot shapes again, after the interior() form and the chunk taper changed the balance
+#include "apps/hotspot.hpp"
+using H1 = Shaped<Hotspot, 2, 8, 4>;
+using H2 = Shaped<Hotspot, 2, 8, 2>;
+using H3 = Shaped<Hotspot, 2, 12, 4>;
+using H4 = Shaped<Hotspot, 1, 12, 4>;
+using H5 = Shaped<Hotspot, 3, 8, 4>;
+using H6 = Shaped<Hotspot, 2, 6, 4>;
+using H7 = Shaped<Hotspot, 1, 8, 4>;
+STSTHIP_REGISTER_APP("x_hs_soa_k2t8p4", H1, true);
+STSTHIP_REGISTER_APP("x_hs_soa_k2t8p2", H2, true);
+STSTHIP_REGISTER_APP("x_hs_soa_k2t12p4", H3, true);
+STSTHIP_REGISTER_APP("x_hs_soa_k1t12p4", H4, true);
+STSTHIP_REGISTER_APP("x_hs_soa_k3t8p4", H5, true);
+STSTHIP_REGISTER_APP("x_hs_soa_k2t6p4", H6, true);
+STSTHIP_REGISTER_APP("x_hs_soa_k1t8p4", H7, true);
+STSTHIP_REGISTER_APP("x_hs_aos_k2t12p4", H3, false);
+STSTHIP_REGISTER_APP("x_hs_aos_k3t8p4", H5, false);
+STSTHIP_REGISTER_APP("x_hs_aos_k1t12p4", H4, false);

@@ -72,4 +72,17 @@ template <std::size_t radius> struct SelfCheck {
 };
 
 } // namespace apps
+
+namespace hip {
+template <typename F, bool SOA> struct SweepTuning;
+// 25 comparisons per neighbour: the kernel is register-bound long before the heuristic's window is
+// (T = 4: 248 VGPRs).  Correctness only, so the shallow pipeline stays.
+template <bool SOA> struct SweepTuning<apps::SelfCheck<1>, SOA> {
+    static constexpr int cells_per_lane = 1;
+    static constexpr int max_generations = 4;
+    static constexpr int prefetch_rows = 4;
+    static constexpr bool interior_variant = true;
+    static constexpr int min_waves_per_simd = 1;
+};
+} // namespace hip
 } // namespace stencil

@@ -6,8 +6,19 @@
 #include <StencilStream/cuda/StencilUpdate.hpp>
 #include <StencilStream/cuda/internal/Helpers.hpp>
 #include <apps/conway.hpp>
+#include <cstring>
 
 using namespace stencil;
+
+// the self-checking cell has five words, for which the backend would decline the split request; the tests
+// below want the per-field planes exercised through the templates
+namespace stencil {
+namespace hip {
+template <> struct SplitCellPolicy<apps::SelfCheck<1>> {
+    static constexpr bool sweep_on_planes = true;
+};
+} // namespace hip
+} // namespace stencil
 
 static_assert(concepts::Grid<hip::Grid<bool>, bool>);
 static_assert(concepts::StencilUpdate<cuda::StencilUpdate<apps::Conway>, apps::Conway, cuda::Grid<bool>>);
@@ -73,6 +84,60 @@ static void test_zero_iterations_alias() {
     REQUIRE(in[1][1] == true);
 }
 
+// split_cell_structure = true is a request for per-field planes; the backend honours it for thin cells and
+// sweeps fat cells (four words and more) as AoS, with identical results (hip::SplitCellPolicy)
+struct FatCell {
+    float a, b, c, d;
+    static constexpr auto fields = std::make_tuple(&FatCell::a, &FatCell::b, &FatCell::c, &FatCell::d);
+};
+struct FatShift : public BaseTransitionFunction {
+    using Cell = FatCell;
+    FatCell operator()(Stencil<FatCell, 1> const &s) const {
+        return FatCell{s[0][-1].a, s[-1][0].b + 1.0f, s[0][0].c * 0.5f, s[0][0].d + s[0][1].a};
+    }
+};
+static_assert(!hip::SplitCellPolicy<FatShift>::sweep_on_planes);
+static_assert(hip::SplitCellPolicy<apps::SelfCheck<2>>::sweep_on_planes == false);
+
+static void test_split_request_on_fat_cells() {
+    const std::size_t h = 70, w = 131;
+    hip::Grid<FatCell> grid(h, w);
+    {
+        hip::Grid<FatCell>::GridAccessor<sycl::access::mode::read_write> ac(grid);
+        for (std::size_t r = 0; r < h; r++)
+            for (std::size_t c = 0; c < w; c++)
+                ac[r][c] = FatCell{float(r), float(c), float(r + c), 1.0f};
+    }
+    auto run = [&](auto &update) { return update(grid); };
+    hip::StencilUpdate<FatShift, true> split({.transition_function = FatShift(),
+                                              .halo_value = FatCell{-1.0f, -2.0f, -3.0f, -4.0f},
+                                              .n_iterations = 11,
+                                              .blocking = true});
+    hip::StencilUpdate<FatShift, false> plain({.transition_function = FatShift(),
+                                               .halo_value = FatCell{-1.0f, -2.0f, -3.0f, -4.0f},
+                                               .n_iterations = 11,
+                                               .blocking = true});
+    hip::Grid<FatCell> a = run(split), b = run(plain);
+    bool same = true;
+    {
+        hip::Grid<FatCell>::GridAccessor<sycl::access::mode::read> x(a), y(b);
+        for (std::size_t r = 0; r < h; r++)
+            for (std::size_t c = 0; c < w; c++)
+                same = same && std::memcmp(&x[r][c], &y[r][c], sizeof(FatCell)) == 0;
+    }
+    REQUIRE(same);
+    // zero iterations: the split path returns a fresh grid (cuda/StencilUpdate.hpp:285,440), never an alias
+    split.get_params().n_iterations = 0;
+    hip::Grid<FatCell> copy = split(grid);
+    {
+        hip::Grid<FatCell>::GridAccessor<sycl::access::mode::read_write> ac(copy);
+        REQUIRE(ac[3][4].a == 3.0f && ac[3][4].b == 4.0f);
+        ac[3][4].a = 99.0f;
+    }
+    hip::Grid<FatCell>::GridAccessor<sycl::access::mode::read> in(grid);
+    REQUIRE(in[3][4].a == 3.0f);
+}
+
 static void test_field_buffers() {
     // cuda/internal/Helpers.hpp:37-67: one typed plane per field, zipped iteration
     auto buffers = cuda::internal::alloc_field_buffers<apps::SelfCheckCell>(1000);
@@ -102,5 +167,6 @@ int main() {
                                          hip::StencilUpdate<apps::SelfCheck<1>, true>>();
     test_user_functor();
     test_zero_iterations_alias();
+    test_split_request_on_fat_cells();
     return finish("hip_api_test");
 }
