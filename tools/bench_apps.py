@@ -67,6 +67,13 @@ def main():
                 p.coef[i] = 0.2
             halo = np.float32(0).tobytes()
             pa, pb = [torch.rand(H, W, device=dev)], [torch.empty(H, W, device=dev)]
+        elif name == "jacobi_general":
+            app, H, W, gens = "jacobi5general", 16384, 16384, 240
+            p = capi.JacobiParams()
+            for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
+                p.coef[i] = c
+            halo = np.float32(0).tobytes()
+            pa, pb = [torch.rand(H, W, device=dev)], [torch.empty(H, W, device=dev)]
         elif name in ("hotspot", "hotspot_aos"):
             app, H, W, gens = name, 8192, 8192, 200
             p = hotspot_params(H)
