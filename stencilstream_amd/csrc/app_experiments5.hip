@@ -31,3 +31,16 @@ STSTHIP_REGISTER_APP("x_hs_soa_k1t8p4", H7, true);
 STSTHIP_REGISTER_APP("x_hs_aos_k2t12p4", H3, false);
 STSTHIP_REGISTER_APP("x_hs_aos_k3t8p4", H5, false);
 STSTHIP_REGISTER_APP("x_hs_aos_k1t12p4", H4, false);
+
+// HotSpot in fp64 is HBM bound at T = 8 (5.1 TB/s, profiles/r01_apps_summary.json): deeper launches move fewer
+// bytes per generation but produce fewer of the 64 columns a wave loads
+using Hotspot64 = HotspotT<double>;
+using D1 = Shaped<Hotspot64, 1, 12, 4>;
+using D2 = Shaped<Hotspot64, 1, 10, 4>;
+using D3 = Shaped<Hotspot64, 1, 16, 4>;
+using D4 = Shaped<Hotspot64, 1, 12, 2>;
+STSTHIP_REGISTER_APP("x_h64_soa_k1t12p4", D1, true);
+STSTHIP_REGISTER_APP("x_h64_soa_k1t10p4", D2, true);
+STSTHIP_REGISTER_APP("x_h64_soa_k1t16p4", D3, true);
+STSTHIP_REGISTER_APP("x_h64_soa_k1t12p2", D4, true);
+STSTHIP_REGISTER_APP("x_h64_aos_k1t12p4", D1, false);

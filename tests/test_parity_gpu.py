@@ -381,6 +381,54 @@ def test_native_comm_single_rank(gpu):
     capi.check(lib.ststhip_comm_destroy(comm), "ststhip_comm_destroy")
 
 
+def test_conway_full_size_word_form(gpu, oracle, monkeypatch):
+    """Game of Life at 16384^2 (the size of the headline grid): the word form (four cells per 32-bit word, two
+    row strips, 8 generations per launch) equals the byte-per-register kernel bit for bit; windows of the
+    result equal the oracle on the window plus a margin of n cells; and a period-2 pattern (blinkers on a
+    dead background) comes back after an even number of generations."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    N, n = 16384, 20
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    src = (torch.rand(N, N, device=gpu, generator=gen) < 0.37).to(torch.uint8)
+    words, cells = torch.empty_like(src), torch.empty_like(src)
+    dom = capi.Domain(N, N, 0, N, N)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("STSTHIP_CONWAY_FASTPATH", "1")
+    capi.app_run("conway", capi.NoParams(), b"\0", dom, [src.data_ptr()], [words.data_ptr()], 0, n, blocking=True,
+                 stream=s.cuda_stream)
+    monkeypatch.setenv("STSTHIP_CONWAY_FASTPATH", "0")
+    capi.app_run("conway", capi.NoParams(), b"\0", dom, [src.data_ptr()], [cells.data_ptr()], 0, n, blocking=True,
+                 stream=s.cuda_stream)
+    assert torch.equal(words, cells)
+    assert 0 < int(words.sum()) < N * N and int(words.max()) == 1
+
+    m, w = n, 80
+    for r0, c0 in ((0, 0), (0, N - w), (N - w, 0), (N - w, N - w), (N // 2, N // 2), (6553, 0), (0, 9830),
+                   (N * 2 // 5 - 40, 4000)):  # the last one straddles the boundary of the two row strips
+        ra, rb = max(0, r0 - m), min(N, r0 + w + m)
+        ca, cb = max(0, c0 - m), min(N, c0 + w + m)
+        ref = oracle.conway(src[ra:rb, ca:cb].cpu().numpy(), n, n_threads=8)
+        got = words[r0:r0 + w, c0:c0 + w].cpu().numpy()
+        assert np.array_equal(got, ref[r0 - ra:r0 - ra + w, c0 - ca:c0 - ca + w]), (r0, c0)
+
+    monkeypatch.setenv("STSTHIP_CONWAY_FASTPATH", "1")
+    blink = torch.zeros(N, N, dtype=torch.uint8, device=gpu)
+    blink[2::8, 1::8] = 1
+    blink[2::8, 2::8] = 1
+    blink[2::8, 3::8] = 1
+    out = torch.empty_like(blink)
+    capi.app_run("conway", capi.NoParams(), b"\0", dom, [blink.data_ptr()], [out.data_ptr()], 0, 38, blocking=True,
+                 stream=s.cuda_stream)
+    assert torch.equal(out, blink)
+    capi.app_run("conway", capi.NoParams(), b"\0", dom, [blink.data_ptr()], [out.data_ptr()], 0, 7, blocking=True,
+                 stream=s.cuda_stream)
+    assert not torch.equal(out, blink) and int(out.sum()) == int(blink.sum())
+
+
 def test_baseline_size_properties(gpu, oracle):
     """BASELINE config 1 size (Jacobi5General 16384^2): (1) temporal blocking is invisible -- the
     8-generations-per-launch path equals the 1-generation-per-launch path bit for bit; (2) windows of the

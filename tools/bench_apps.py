@@ -87,12 +87,12 @@ def main():
                 cells = torch.zeros(H, W, 2, device=dev)
                 cells[..., 0] = 30.0
                 pa, pb = [cells], [torch.empty_like(cells)]
-        elif name in ("hotspot_f64", "hotspot_f64_aos"):
-            app, H, W, gens = name, 8192, 8192, 200
+        elif name in ("hotspot_f64", "hotspot_f64_aos") or name.startswith("x_h64_"):
+            app, H, W, gens = name, 8192, 8192, (240 if name.startswith("x_h64_") else 200)
             p32 = hotspot_params(H)
             p = capi.HotspotParamsF64(p32.Rx_1, p32.Ry_1, p32.Rz_1, p32.Cap_1)
             halo = np.zeros(2, np.float64).tobytes()
-            if name == "hotspot_f64":
+            if name == "hotspot_f64" or "_soa_" in name:
                 temp = torch.full((H, W), 30.0, device=dev, dtype=torch.float64)
                 power = torch.zeros(H, W, device=dev, dtype=torch.float64)
                 power[H // 4 - 1:3 * H // 4, W // 4 - 1:3 * W // 4] = 0.5
