@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--single-strip", action="store_true",
                     help="one full-grid launch per pass (no row strips on side streams); used for profiling")
     ap.add_argument("--cpu-size", type=int, default=8192)
-    ap.add_argument("--cpu-generations", type=int, default=16)
+    ap.add_argument("--cpu-generations", type=int, default=192)
     return ap.parse_args()
 
 

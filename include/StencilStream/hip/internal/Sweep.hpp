@@ -80,6 +80,21 @@ template <typename Cell, int I> inline std::size_t field_offset() {
 
 constexpr int max_planes = 16;
 
+// Results are not read again before the next pass (a whole grid later).  Storing them with the non-temporal
+// hint leaves L2 to the input rows neighbouring waves share; whether that pays is a property of the kernel
+// (streaming_stores_for below).
+template <bool STREAMING, typename T, int N> STST_DEVICE inline void store_cells(T *to, T const (&from)[N]) {
+    if constexpr (STREAMING && (N * sizeof(T)) % 4 == 0) {
+        std::uint32_t words[N * sizeof(T) / 4];
+        __builtin_memcpy(words, from, sizeof words);
+#pragma unroll
+        for (unsigned i = 0; i < N * sizeof(T) / 4; i++)
+            __builtin_nontemporal_store(words[i], reinterpret_cast<std::uint32_t *>(to) + i);
+    } else {
+        __builtin_memcpy(to, from, N * sizeof(T)); // typed pointers: the alignment of T decides the store width
+    }
+}
+
 // Device pointers of one grid: a single AoS plane of cells, or one dense plane per field.
 template <typename Cell, bool SOA> struct PlaneSet;
 
@@ -96,8 +111,9 @@ template <typename Cell> struct PlaneSet<Cell, false> {
     STST_DEVICE void load_one(std::size_t at, Cell &cell) const {
         cell = static_cast<const Cell *>(plane[0])[at];
     }
-    template <int K> STST_DEVICE void store(std::size_t first, Cell const (&cells)[K]) const {
-        __builtin_memcpy(static_cast<Cell *>(plane[0]) + first, cells, K * sizeof(Cell));
+    template <int K, bool STREAMING = false>
+    STST_DEVICE void store(std::size_t first, Cell const (&cells)[K]) const {
+        store_cells<STREAMING>(static_cast<Cell *>(plane[0]) + first, cells);
     }
     STST_DEVICE void store_one(std::size_t at, Cell const &cell) const {
         static_cast<Cell *>(plane[0])[at] = cell;
@@ -139,7 +155,8 @@ template <typename Cell> struct PlaneSet<Cell, true> {
             cell.*member = static_cast<const E *>(plane[f])[at];
         });
     }
-    template <int K> STST_DEVICE void store(std::size_t first, Cell const (&cells)[K]) const {
+    template <int K, bool STREAMING = false>
+    STST_DEVICE void store(std::size_t first, Cell const (&cells)[K]) const {
         static_for<0, n_planes>([&](auto f) __attribute__((always_inline)) {
             using E = FieldType<Cell, f>;
             constexpr auto member = field_pointer<Cell, f>();
@@ -147,7 +164,7 @@ template <typename Cell> struct PlaneSet<Cell, true> {
 #pragma unroll
             for (int k = 0; k < K; k++)
                 values[k] = static_cast<E>(cells[k].*member);
-            __builtin_memcpy(static_cast<E *>(plane[f]) + first, values, K * sizeof(E));
+            store_cells<STREAMING>(static_cast<E *>(plane[f]) + first, values);
         });
     }
     STST_DEVICE void store_one(std::size_t at, Cell const &cell) const {
@@ -208,6 +225,7 @@ template <typename Cell, bool SOA> constexpr int cell_words() {
 //   prefetch_rows (P)    rows loaded ahead; must be a multiple of 2*radius
 //   interior_variant     also build the check-free code path for waves away from the grid edge
 //   min_waves_per_simd   occupancy the register allocator must allow (second __launch_bounds__ argument)
+//   streaming_stores     (optional member) store results with the non-temporal hint (streaming_stores_for below)
 //   trapezoid_fill       (optional member) skip the levels that are not due yet while a wave's pipeline fills;
 //                        default: cells of up to four words per generation (measured: Jacobi +3 %, HotSpot
 //                        +5 %, Conway +4 %, FDTD -2..-8 %: profiles/r01_ab_trapezoid_fill.txt)
@@ -288,6 +306,19 @@ template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
         return SweepTuning<F, SOA>::trapezoid_fill;
     else
         return cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 4;
+}
+
+// Non-temporal stores of the results (SweepTuning<F, SOA>::streaming_stores, optional member).  Measured
+// (profiles/r01_ab_nt_stores.txt): +1.2..1.6 % Jacobi, +1..5 % HotSpot fp32, +2..4 % HotSpot fp64 on planes; but
+// -8 % FDTD on planes, -1 % FDTD / HotSpot fp64 as AoS and -3 % for the packed Game of Life -- the kernels that are
+// bound by HBM or store narrow rows pay for partial lines that L2 no longer merges.  Default: cells of up to two
+// 32-bit words per generation that are at least one word wide.
+template <typename F, bool SOA> constexpr bool streaming_stores_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::streaming_stores; })
+        return SweepTuning<F, SOA>::streaming_stores;
+    else
+        return sizeof(typename F::Cell) >= 4 &&
+               cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 2;
 }
 
 template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> struct Sweep {
@@ -482,7 +513,7 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                     const std::size_t first =
                         std::size_t(j - g.row_origin) * g.pitch + std::size_t(std::int64_t(x0));
                     if (!EDGE || vec_in) {
-                        a.dst.template store<K>(first, cur);
+                        a.dst.template store<K, streaming_stores_for<F, SOA>()>(first, cur);
                     } else {
 #pragma unroll
                         for (int k = 0; k < K; k++)

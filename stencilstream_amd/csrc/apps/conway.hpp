@@ -57,4 +57,18 @@ struct ConwayPacked : public BaseTransitionFunction {
 };
 
 } // namespace apps
+
+namespace hip {
+template <typename F, bool SOA> struct SweepTuning;
+// K = 4 words, T = 8 is the best of eight shapes (profiles/r01_tune_conway_packed.txt); plain stores: the
+// non-temporal ones lose 3 % here (profiles/r01_ab_nt_stores.txt)
+template <> struct SweepTuning<apps::ConwayPacked, false> {
+    static constexpr int cells_per_lane = 4;
+    static constexpr int max_generations = 8;
+    static constexpr int prefetch_rows = 4;
+    static constexpr bool interior_variant = true;
+    static constexpr int min_waves_per_simd = 1;
+    static constexpr bool streaming_stores = false;
+};
+} // namespace hip
 } // namespace stencil
