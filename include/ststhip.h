@@ -185,7 +185,11 @@ typedef struct {
  * arrays of n_planes device pointers of geometry `dom` (row_origin 0, local_rows = height).
  * Scratch planes come from the runtime's pool.  blocking != 0 synchronises the stream before
  * returning; profiling != 0 brackets every sweep kernel with HIP events.  n_iterations == 0
- * copies src to dst. */
+ * copies src to dst.
+ * Two applications have a second, bit-identical form the call switches to on its own:
+ * "jacobi5general" with five equal positive coefficients and a +0 halo (product-carrying form),
+ * and "conway" with halo = false, width and pitch multiples of four and 4-byte aligned planes
+ * (four cells per 32-bit word).  Cells of "conway" are C++ bools: bytes 0 or 1, nothing else. */
 int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cell,
                     const ststhip_domain *dom, const void *const *src, void *const *dst,
                     uint64_t iteration_offset, uint64_t n_iterations, int blocking,
