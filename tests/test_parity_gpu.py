@@ -381,6 +381,66 @@ def test_native_comm_single_rank(gpu):
     capi.check(lib.ststhip_comm_destroy(comm), "ststhip_comm_destroy")
 
 
+RANDOM_CASES = list(range(48))
+
+
+@pytest.mark.parametrize("case", RANDOM_CASES)
+def test_random_configurations(gpu, oracle, case):
+    """Seeded random draws over application, layout, grid shape (ragged widths, single rows and columns, widths
+    around the strip widths of the kernels), generation count (every mix of launch depths), iteration offset and
+    halo value: the HIP path equals the oracle bit for bit."""
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(0xA11CE + case)
+    kind = ["jacobi5", "jacobi_variant", "hotspot", "conway", "fdtd", "jacobi_uniform"][case % 6]
+    widths = [1, 2, 3, 5, 47, 48, 49, 112, 167, 168, 169, 239, 240, 241, 256, 333, 480, 700, 1024]
+    H = int(rng.choice([1, 2, 3, 7, 24, 25, 100, 133, 134, 300, 611]))
+    W = int(rng.choice(widths))
+    if kind == "conway":
+        W = int(rng.choice([4, 8, 236, 240, 244, 960, 1028, 3, 5, 241]))
+    n = int(rng.integers(0, 45))
+    offset = int(rng.choice([0, 0, 1, 7, 1000]))
+    what = f"{kind} {H}x{W} n={n} offset={offset}"
+    if kind in ("jacobi5", "jacobi_uniform"):
+        grid = rng.random((H, W), dtype=np.float32) * 4 - 1
+        coef = [0.3] * 5 if kind == "jacobi_uniform" else list(rng.random(5, dtype=np.float32) * 0.4)
+        halo = 0.0 if kind == "jacobi_uniform" else float(np.float32(rng.random() * 2 - 1))
+        got = run_hip(U.jacobi("Jacobi5General", coef), grid, n, halo=np.float32(halo), offset=offset)
+        want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=halo, iteration_offset=offset, n_threads=8)
+    elif kind == "jacobi_variant":
+        variant, ncoef = [("Jacobi1General", 1), ("Jacobi3Constant", 0), ("Jacobi5Constant", 0), ("Jacobi4General", 4),
+                          ("Jacobi9General", 9)][int(rng.integers(0, 5))]
+        grid = rng.random((H, W), dtype=np.float32)
+        coef = list(rng.random(ncoef, dtype=np.float32) * 0.2)
+        halo = float(np.float32(rng.random()))
+        what += " " + variant
+        got = run_hip(U.jacobi(variant, coef), grid, n, halo=np.float32(halo), offset=offset)
+        want = oracle.jacobi(variant, coef, grid, n, halo=halo, iteration_offset=offset, n_threads=8)
+    elif kind == "hotspot":
+        cells = np.zeros((H, W), dtype=U.HOTSPOT_CELL)
+        cells["temp"] = 300 + 40 * rng.random((H, W), dtype=np.float32)
+        cells["power"] = rng.random((H, W), dtype=np.float32) * 0.02
+        p = oracle.hotspot_params(H, W)
+        split = bool(rng.integers(0, 2))
+        what += f" split={split}"
+        got = run_hip(U.hotspot(p.Rx_1, p.Ry_1, p.Rz_1, p.Cap_1, split_cell_structure=split), cells, n, offset=offset)
+        want = oracle.hotspot(p, cells, n, iteration_offset=offset, n_threads=8)
+    elif kind == "conway":
+        grid = (rng.random((H, W)) < rng.choice([0.2, 0.37, 0.6])).astype(np.uint8)
+        got = run_hip(U.conway(), grid, n, offset=offset)
+        want = oracle.conway(grid, n, n_threads=8)
+    else:
+        H, W = max(H, 8), max(W, 8)
+        po, pc, cells = fdtd_setup(oracle, H, W)
+        for f in ("ex", "ey", "hz"):
+            cells[f] = (rng.random((H, W), dtype=np.float32) - 0.5) * 1e-3
+        split = bool(rng.integers(0, 2))
+        what += f" {H}x{W} split={split}"
+        got = run_hip(U.fdtd(pc, split), cells, n, halo=np.zeros((), dtype=U.FDTD_CELL), offset=offset)
+        want = oracle.fdtd(po, cells, n, iteration_offset=offset, n_threads=8)
+    assert np.array_equal(bits(got), bits(want)), what
+
+
 def test_conway_full_size_word_form(gpu, oracle, monkeypatch):
     """Game of Life at 16384^2 (the size of the headline grid): the word form (four cells per 32-bit word, two
     row strips, 8 generations per launch) equals the byte-per-register kernel bit for bit; windows of the
