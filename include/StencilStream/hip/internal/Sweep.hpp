@@ -111,11 +111,11 @@ template <typename Cell> struct PlaneSet<Cell, false> {
     STST_DEVICE void load_one(std::size_t at, Cell &cell) const {
         cell = static_cast<const Cell *>(plane[0])[at];
     }
-    template <int K, bool STREAMING = false>
+    template <int K, bool STREAMING = false, std::uint32_t = 0>
     STST_DEVICE void store(std::size_t first, Cell const (&cells)[K]) const {
         store_cells<STREAMING>(static_cast<Cell *>(plane[0]) + first, cells);
     }
-    STST_DEVICE void store_one(std::size_t at, Cell const &cell) const {
+    template <std::uint32_t = 0> STST_DEVICE void store_one(std::size_t at, Cell const &cell) const {
         static_cast<Cell *>(plane[0])[at] = cell;
     }
 };
@@ -155,11 +155,14 @@ template <typename Cell> struct PlaneSet<Cell, true> {
             cell.*member = static_cast<const E *>(plane[f])[at];
         });
     }
-    template <int K, bool STREAMING = false>
+    // SKIP_MASK: planes that already hold these values and are not stored (bit f = plane f)
+    template <int K, bool STREAMING = false, std::uint32_t SKIP_MASK = 0>
     STST_DEVICE void store(std::size_t first, Cell const (&cells)[K]) const {
         static_for<0, n_planes>([&](auto f) __attribute__((always_inline)) {
             using E = FieldType<Cell, f>;
             constexpr auto member = field_pointer<Cell, f>();
+            if constexpr ((SKIP_MASK >> int(f)) & 1u)
+                return;
             E values[K];
 #pragma unroll
             for (int k = 0; k < K; k++)
@@ -167,10 +170,12 @@ template <typename Cell> struct PlaneSet<Cell, true> {
             store_cells<STREAMING>(static_cast<E *>(plane[f]) + first, values);
         });
     }
-    STST_DEVICE void store_one(std::size_t at, Cell const &cell) const {
+    template <std::uint32_t SKIP_MASK = 0> STST_DEVICE void store_one(std::size_t at, Cell const &cell) const {
         static_for<0, n_planes>([&](auto f) __attribute__((always_inline)) {
             using E = FieldType<Cell, f>;
             constexpr auto member = field_pointer<Cell, f>();
+            if constexpr ((SKIP_MASK >> int(f)) & 1u)
+                return;
             static_cast<E *>(plane[f])[at] = static_cast<E>(cell.*member);
         });
     }
@@ -308,6 +313,30 @@ template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
         return cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 4;
 }
 
+// A transition function may declare fields it only copies from the centre cell,
+//     static constexpr auto constant_fields = std::make_tuple(&Cell::power);
+// (an extension: the reference's API has no such hint, cuda/StencilUpdate.hpp:387-392 stores every field in
+// every sweep).  With per-field planes the pass driver's targets alternate between two buffers, so from the
+// third pass of a run on the target planes of those fields already hold their values and the stores are left
+// out: a quarter of the HBM bytes of HotSpot and FDTD, which run at the practical HBM rate.
+template <typename F> constexpr std::uint32_t constant_plane_mask() {
+    std::uint32_t mask = 0;
+    if constexpr (requires { F::constant_fields; } && SplittableCell<typename F::Cell>) {
+        using Cell = typename F::Cell;
+        constexpr int n_constant = int(std::tuple_size_v<std::remove_cvref_t<decltype(F::constant_fields)>>);
+        static_for<0, field_count<Cell>()>([&](auto f) {
+            static_for<0, n_constant>([&](auto c) {
+                using A = std::remove_cvref_t<decltype(std::get<f>(Cell::fields))>;
+                using B = std::remove_cvref_t<decltype(std::get<c>(F::constant_fields))>;
+                if constexpr (std::is_same_v<A, B>)
+                    if (std::get<f>(Cell::fields) == std::get<c>(F::constant_fields))
+                        mask |= 1u << int(f);
+            });
+        });
+    }
+    return mask;
+}
+
 // Non-temporal stores of the results (SweepTuning<F, SOA>::streaming_stores, optional member).  Measured
 // (profiles/r01_ab_nt_stores.txt): +1.2..1.6 % Jacobi, +1..5 % HotSpot fp32, +2..4 % HotSpot fp64 on planes; but
 // -8 % FDTD on planes, -1 % FDTD / HotSpot fp64 as AoS and -3 % for the packed Game of Life -- the kernels that are
@@ -351,9 +380,12 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
         SweepGeometry geo;
     };
 
-    template <bool EDGE>
+    // SKIP_CONSTANTS: the target planes of F::constant_fields already hold their values (see
+    // constant_plane_mask); their stores are left out
+    template <bool EDGE, bool SKIP_CONSTANTS>
     STST_DEVICE static void run(Args const &a, const int lane, const int strip, const int ya,
                                 const int yb) {
+        constexpr std::uint32_t skip_mask = SKIP_CONSTANTS ? constant_plane_mask<F>() : 0u;
         SweepGeometry const &g = a.geo;
         const int x0 = strip * OW - GX + lane * K; // global column of the lane's first cell
         const int ystart = ya - G;
@@ -513,12 +545,12 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                     const std::size_t first =
                         std::size_t(j - g.row_origin) * g.pitch + std::size_t(std::int64_t(x0));
                     if (!EDGE || vec_in) {
-                        a.dst.template store<K, streaming_stores_for<F, SOA>()>(first, cur);
+                        a.dst.template store<K, streaming_stores_for<F, SOA>(), skip_mask>(first, cur);
                     } else {
 #pragma unroll
                         for (int k = 0; k < K; k++)
                             if (col_in[k])
-                                a.dst.store_one(first + k, cur[k]);
+                                a.dst.template store_one<skip_mask>(first + k, cur[k]);
                     }
                 }
         };
@@ -533,7 +565,7 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
             static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, it, std::false_type{}); });
     }
 
-    STST_DEVICE static void entry(Args const &a) {
+    template <bool SKIP_CONSTANTS = false> STST_DEVICE static void entry(Args const &a) {
         SweepGeometry const &g = a.geo;
         const int lane = int(threadIdx.x) & (wave_size - 1);
         // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, each with its own
@@ -570,19 +602,19 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
             const bool interior =
                 xw0 >= 0 && xw0 + LW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
             if (interior)
-                run<false>(a, lane, strip, ya, yb);
+                run<false, SKIP_CONSTANTS>(a, lane, strip, ya, yb);
             else
-                run<true>(a, lane, strip, ya, yb);
+                run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb);
         } else {
-            run<true>(a, lane, strip, ya, yb);
+            run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb);
         }
     }
 };
 
 // MIN_WAVES = waves per SIMD the register allocator must leave room for (launch-bounds semantics).
-template <typename SW, int MIN_WAVES = 1>
+template <typename SW, int MIN_WAVES = 1, bool SKIP_CONSTANTS = false>
 __global__ void __launch_bounds__(256, MIN_WAVES) sweep_kernel(const typename SW::Args args) {
-    SW::entry(args);
+    SW::template entry<SKIP_CONSTANTS>(args);
 }
 
 // ------------------------------------------------------------------ host side
@@ -700,6 +732,10 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     static int resident_blocks = 0; // per kernel instantiation
     if (resident_blocks == 0)
         check(ststhip_occupancy(kernel, waves_per_block * wave_size, 0, &resident_blocks), "occupancy query");
+    // per-field planes of fields F only copies: from the third pass of a run on the target holds them already
+    if constexpr (SOA && constant_plane_mask<F>() != 0)
+        if (ststhip_target_holds_constants() && env_int("STSTHIP_SKIP_CONSTANT_STORES", 1))
+            kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, true>);
     g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW);
     g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), g.n_strips, SW::G, resident_blocks,
                                    int(waves_per_block));

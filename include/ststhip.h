@@ -105,6 +105,11 @@ int ststhip_occupancy(const void *function, unsigned block_threads, size_t share
  * ststhip_run_passes).  The launcher sizes its row chunks with it: concurrent launches share the
  * chip and hide each other's tails, so longer chunks (fewer warm-up rows) pay. */
 int ststhip_launch_concurrency(void);
+/* 1 while the pass driver is in a pass whose target planes were already written, row for row, by the pass
+ * before the previous one of the same call (the third pass of a run and every later one); 0 otherwise.  The
+ * sweep launcher then leaves out the stores of the per-field planes a transition function declares constant
+ * (F::constant_fields): they already hold those values. */
+int ststhip_target_holds_constants(void);
 /* A host that runs row-range sweeps side by side itself (the multi-GPU strip driver,
  * stencilstream_amd/dist.py) states their number here for the calling thread; 1 resets it. */
 int ststhip_set_launch_concurrency(int n_launches_side_by_side);

@@ -162,6 +162,7 @@ def load():
         "ststhip_launch": [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, pp, sz, vp],
         "ststhip_occupancy": [vp, C.c_uint, sz, C.POINTER(C.c_int)],
         "ststhip_launch_concurrency": [],
+        "ststhip_target_holds_constants": [],
         "ststhip_set_launch_concurrency": [C.c_int],
         "ststhip_suggest_row_strips": [C.c_char_p, u64, u64, u64],
         "ststhip_scatter_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],

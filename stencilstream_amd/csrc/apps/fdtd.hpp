@@ -29,6 +29,10 @@ struct Fdtd {
 
     Block p;
 
+    // the material coefficients are copied through unchanged (Kernel.hpp:94-140 never assigns them)
+    static constexpr auto constant_fields =
+        std::make_tuple(&FdtdCell::ca, &FdtdCell::cb, &FdtdCell::da, &FdtdCell::db);
+
     static Fdtd from_params(Block const &block) { return Fdtd{block}; }
 
     // host side, once per iteration (Kernel.hpp:80-84): float arithmetic, libm cosf/expf

@@ -26,6 +26,9 @@ template <typename Real> struct HotspotT : public BaseTransitionFunction {
 
     Real Rx_1, Ry_1, Rz_1, Cap_1;
 
+    // `power` is copied through unchanged (hotspot.cpp:96): the planes layout need not store it again
+    static constexpr auto constant_fields = std::make_tuple(&Cell::power);
+
     static HotspotT from_params(Block const &p) {
         HotspotT h;
         h.Rx_1 = p.Rx_1;

@@ -567,7 +567,9 @@ int ststhip_occupancy(const void *function, unsigned block_threads, size_t share
 }
 
 static thread_local int g_launch_concurrency = 1;
+static thread_local int g_target_holds_constants = 0;
 int ststhip_launch_concurrency(void) { return g_launch_concurrency; }
+int ststhip_target_holds_constants(void) { return g_target_holds_constants; }
 int ststhip_set_launch_concurrency(int n) {
     g_launch_concurrency = std::min(std::max(n, 1), 8);
     return STSTHIP_OK;
@@ -809,6 +811,9 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         for (std::size_t pass = 0; pass < depths.size() && rc == STSTHIP_OK; pass++) {
             const bool into_dst = ((depths.size() - 1 - pass) % 2) == 0;
             void *const *to = into_dst ? dst : scratch;
+            // targets alternate, and every pass writes all rows: from the third pass on the target already holds
+            // what the pass before the previous one stored there, in particular the fields that never change
+            g_target_holds_constants = pass >= 2 ? 1 : 0;
             const std::uint64_t g = std::uint64_t(depths[pass]) * desc->halo_depth_per_generation;
             hipEvent_t t0 = nullptr, t1 = nullptr;
             if (profiling) {
@@ -856,6 +861,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             iteration += depths[pass];
         }
         g_launch_concurrency = 1;
+        g_target_holds_constants = 0;
         // join: the caller's stream continues after every strip has finished
         for (int v = 1; v < strips; v++) {
             hipEvent_t done = new_event();

@@ -381,6 +381,39 @@ def test_native_comm_single_rank(gpu):
     capi.check(lib.ststhip_comm_destroy(comm), "ststhip_comm_destroy")
 
 
+@pytest.mark.parametrize("strips", ["1", "2"])
+def test_constant_field_stores_are_left_out_only_where_safe(gpu, oracle, monkeypatch, strips):
+    """HotSpot and FDTD declare the fields they only copy (constant_fields); on per-field planes their stores are
+    left out from the third pass of a run on.  Results (all fields, fresh target planes from the pool, which hold
+    stale data) equal the oracle with the switch on and off, for one and two row strips and for pass counts
+    around the switch-over."""
+    from stencilstream_amd import update as U
+
+    monkeypatch.setenv("STSTHIP_VIRTUAL_STRIPS", strips)
+    rng = np.random.default_rng(77)
+    shape = (700, 333)
+    cells = np.zeros(shape, dtype=U.HOTSPOT_CELL)
+    cells["temp"] = 320 + 10 * rng.random(shape, dtype=np.float32)
+    cells["power"] = rng.random(shape, dtype=np.float32) * 0.01
+    p = oracle.hotspot_params(*shape)
+    po, pc, fcells = fdtd_setup(oracle, 300, 222)
+    for n in (8, 16, 17, 24, 33, 64):  # HotSpot: 1, 2, 3, 3, 5, 8 passes of up to 8 generations
+        want = oracle.hotspot(p, cells, n, n_threads=8)
+        for switch in ("1", "0"):
+            monkeypatch.setenv("STSTHIP_SKIP_CONSTANT_STORES", switch)
+            # poison the pool's next blocks so that a plane that is wrongly not stored cannot look right
+            junk = U.Grid.from_numpy(np.full(shape, 7.5, dtype=np.float32))
+            del junk
+            got = run_hip(U.hotspot(p.Rx_1, p.Ry_1, p.Rz_1, p.Cap_1, split_cell_structure=True), cells, n)
+            assert np.array_equal(bits(got), bits(want)), f"hotspot n={n} switch={switch}"
+    for n in (6, 12, 13, 18, 31):  # FDTD: 1, 2, 3, 3, 6 passes of up to 6 generations
+        want = oracle.fdtd(po, fcells, n, n_threads=8)
+        for switch in ("1", "0"):
+            monkeypatch.setenv("STSTHIP_SKIP_CONSTANT_STORES", switch)
+            got = run_hip(U.fdtd(pc, True), fcells, n, halo=np.zeros((), dtype=U.FDTD_CELL))
+            assert np.array_equal(bits(got), bits(want)), f"fdtd n={n} switch={switch}"
+
+
 RANDOM_CASES = list(range(48))
 
 
