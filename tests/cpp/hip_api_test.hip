@@ -138,6 +138,58 @@ static void test_split_request_on_fat_cells() {
     REQUIRE(in[3][4].a == 3.0f);
 }
 
+// A user function that declares the field it only copies: on per-field planes the stores of that plane are
+// left out from the third pass of a call on (hip/internal/Sweep.hpp, constant_plane_mask)
+struct Conductor {
+    float temperature, conductivity;
+    static constexpr auto fields = std::make_tuple(&Conductor::temperature, &Conductor::conductivity);
+};
+struct Conduction : public BaseTransitionFunction {
+    using Cell = Conductor;
+    static constexpr auto constant_fields = std::make_tuple(&Conductor::conductivity);
+    Conductor operator()(Stencil<Conductor, 1> const &s) const {
+        const float k = s[0][0].conductivity;
+        const float t = s[0][0].temperature;
+        return Conductor{t + k * (s[-1][0].temperature + s[1][0].temperature + s[0][-1].temperature +
+                                  s[0][1].temperature - 4.0f * t),
+                         k};
+    }
+};
+static_assert(hip::internal::constant_plane_mask<Conduction>() == 2u);
+static_assert(hip::internal::constant_plane_mask<UserHeat>() == 0u);
+static_assert(hip::SplitCellPolicy<Conduction>::sweep_on_planes);
+
+static void test_constant_fields_hint() {
+    const std::size_t h = 300, w = 217;
+    hip::Grid<Conductor> grid(h, w);
+    {
+        hip::Grid<Conductor>::GridAccessor<sycl::access::mode::read_write> ac(grid);
+        for (std::size_t r = 0; r < h; r++)
+            for (std::size_t c = 0; c < w; c++)
+                ac[r][c] = Conductor{float((r * 7 + c * 13) % 50), 0.05f + 0.001f * float((r + 3 * c) % 40)};
+    }
+    for (std::size_t n : {std::size_t(8), std::size_t(17), std::size_t(45)}) { // 1, 3 and 6 passes
+        hip::StencilUpdate<Conduction, true> planes({.transition_function = Conduction(),
+                                                     .halo_value = Conductor{20.0f, 0.0f},
+                                                     .n_iterations = n,
+                                                     .blocking = true});
+        hip::StencilUpdate<Conduction, false> cells({.transition_function = Conduction(),
+                                                     .halo_value = Conductor{20.0f, 0.0f},
+                                                     .n_iterations = n,
+                                                     .blocking = true});
+        hip::Grid<Conductor> a = planes(grid), b = cells(grid);
+        hip::Grid<Conductor>::GridAccessor<sycl::access::mode::read> x(a), y(b), in(grid);
+        bool same = true, kept = true;
+        for (std::size_t r = 0; r < h; r++)
+            for (std::size_t c = 0; c < w; c++) {
+                same = same && std::memcmp(&x[r][c], &y[r][c], sizeof(Conductor)) == 0;
+                kept = kept && x[r][c].conductivity == in[r][c].conductivity;
+            }
+        REQUIRE(same);
+        REQUIRE(kept);
+    }
+}
+
 static void test_field_buffers() {
     // cuda/internal/Helpers.hpp:37-67: one typed plane per field, zipped iteration
     auto buffers = cuda::internal::alloc_field_buffers<apps::SelfCheckCell>(1000);
@@ -168,5 +220,6 @@ int main() {
     test_user_functor();
     test_zero_iterations_alias();
     test_split_request_on_fat_cells();
+    test_constant_fields_hint();
     return finish("hip_api_test");
 }
