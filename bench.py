@@ -3,8 +3,8 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 torch.distributed.run with one rank per GPU.  A "step" is one StencilUpdate call of
-`--generations` generations (default 252 = 21 launches of 12 generations, so the default 4 steps are
-1008 generations, BASELINE.json's 1000 rounded up to whole launches).  Rank 0 prints ONE JSON line.
+`--generations` generations (default 252 = 21 launches of 12 generations; four steps are 1008 generations,
+BASELINE.json's 1000 rounded up to whole launches, and the default 8 steps run that twice).  Rank 0 prints ONE JSON line.
 
 Metric: Gcell-updates/s = H*W*generations / time (sub-iterations not counted), the reference's
 definition (scripts/benchmark-common.jl:97-98,122).  The grid is resident in HBM before the timed
@@ -29,8 +29,8 @@ COEF = [0.2, 0.2, 0.2, 0.2, 0.2]  # examples/jacobi/scripts/benchmark.jl:44-45
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=16384, help="grid columns, and rows per GPU unless --rows-per-gpu")
     ap.add_argument("--rows-per-gpu", type=int, default=0,
                     help="rows of every rank's strip (default: --size); BASELINE config 5 = --size 65536 "
