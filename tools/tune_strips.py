@@ -16,7 +16,7 @@ from stencilstream_amd import capi
 def main():
     app = sys.argv[1] if len(sys.argv) > 1 else "jacobi5general"
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
-    gens = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    gens = int(sys.argv[3]) if len(sys.argv) > 3 else 252
     capi.init(0)
     p = capi.JacobiParams()
     for i in range(5):
@@ -27,7 +27,7 @@ def main():
     halo = np.float32(0).tobytes()
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
-    options = [(1, 500), (2, 500), (2, 400), (2, 333), (2, 250), (2, 150), (2, 600), (2, 700)]
+    options = [(1, 500), (2, 500), (2, 400), (2, 333), (2, 250), (2, 600), (2, 700), (3, 0), (4, 0)]
     times = {v: [] for v in options}
     for rnd in range(5):
         for v in options:
