@@ -11,7 +11,7 @@
 // the walltime covers scratch allocation, scatter, sweeps, gather and -- if `blocking` -- the final
 // synchronisation (:129-139); n_processed_cells does not count sub-iterations (:140-141);
 // split_cell_structure = true scatters the AoS cells into per-field planes, sweeps on those and
-// gathers back (:294-438) -- for cells thin enough that planes pay off (SplitCellPolicy below).
+// gathers back (:294-438) -- except for cells of 16 or 32 bytes with four or more fields, which are swept as AoS (SplitCellPolicy below).
 //
 // What differs by design: instead of one kernel per (iteration, sub-iteration), one kernel
 // advances up to SweepTuning<F>::max_generations generations (hip/internal/Sweep.hpp).
@@ -29,15 +29,20 @@ namespace hip {
 
 // Which layout the sweeps of StencilUpdate<F, true> run on.  The reference's GPU backend needs per-field
 // planes for coalescing because one work-item loads one cell (cuda/StencilUpdate.hpp:346-396).  Here a lane
-// loads whole cells with one vector access, so for fat cells the AoS sweep is the faster one (FDTD, 8 words:
-// 342 vs 270 Gcell/s at 4608^2, profiles/r01_tune_shapes_apps_2.txt) and needs no scatter / gather passes;
-// thin cells keep their planes (HotSpot, 2 words: 1632 vs 1583).  Results are identical either way, so
-// split_cell_structure = true is honoured as a request for planes only where planes pay off.  Specialise to
-// decide differently for a transition function.
+// loads a whole cell, and for cells of 16 or 32 bytes made of four or more fields that is one or two full-width
+// vector accesses instead of many narrow ones: the AoS
+// sweep is then the faster one (FDTD, 32 bytes: 342 vs 270 Gcell/s at 4608^2, profiles/r01_tune_shapes_apps_2.txt;
+// the unchanged example 14.3 -> 11.2 s together with the depth rule) and needs no scatter / gather passes.
+// Thin cells keep their planes (HotSpot, 8 bytes: 1632 vs 1583; in fp64, two 8-byte fields: 1216 vs 1110), and so
+// do cells that do not fill whole vector
+// accesses or are fatter (convection, 88 bytes: 0.34 s on planes against 0.39-0.42 s as AoS cells,
+// profiles/r01_ab_examples.txt).  Results are identical either way, so split_cell_structure = true is honoured as
+// a request for planes except where AoS is known to win.  Specialise to decide differently for a function.
 template <typename F> struct SplitCellPolicy {
     static constexpr bool sweep_on_planes = [] {
         if constexpr (internal::SplittableCell<typename F::Cell>)
-            return internal::cell_words<typename F::Cell, true>() < 4;
+            return !((sizeof(typename F::Cell) == 16 || sizeof(typename F::Cell) == 32) &&
+                     internal::field_count<typename F::Cell>() >= 4);
         else
             return true; // PlaneSet reports the missing Cell::fields
     }();

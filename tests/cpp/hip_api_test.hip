@@ -10,8 +10,7 @@
 
 using namespace stencil;
 
-// the self-checking cell has five words, for which the backend would decline the split request; the tests
-// below want the per-field planes exercised through the templates
+// pinned: the tests below want the per-field planes exercised through the templates whatever the policy says
 namespace stencil {
 namespace hip {
 template <> struct SplitCellPolicy<apps::SelfCheck<1>> {
@@ -84,8 +83,8 @@ static void test_zero_iterations_alias() {
     REQUIRE(in[1][1] == true);
 }
 
-// split_cell_structure = true is a request for per-field planes; the backend honours it for thin cells and
-// sweeps fat cells (four words and more) as AoS, with identical results (hip::SplitCellPolicy)
+// split_cell_structure = true is a request for per-field planes; the backend honours it except for cells of 16
+// or 32 bytes, which it sweeps as AoS with identical results (hip::SplitCellPolicy)
 struct FatCell {
     float a, b, c, d;
     static constexpr auto fields = std::make_tuple(&FatCell::a, &FatCell::b, &FatCell::c, &FatCell::d);
@@ -97,7 +96,7 @@ struct FatShift : public BaseTransitionFunction {
     }
 };
 static_assert(!hip::SplitCellPolicy<FatShift>::sweep_on_planes);
-static_assert(hip::SplitCellPolicy<apps::SelfCheck<2>>::sweep_on_planes == false);
+static_assert(hip::SplitCellPolicy<apps::SelfCheck<2>>::sweep_on_planes); // 20 bytes: planes, as asked
 
 static void test_split_request_on_fat_cells() {
     const std::size_t h = 70, w = 131;
