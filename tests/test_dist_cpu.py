@@ -29,9 +29,11 @@ class OracleSweep:
     max_generations = 4
     halo_per_generation = 1
 
-    def __init__(self, kind, coef=None):
-        self.kind, self.coef = kind, coef
+    def __init__(self, kind, coef=None, shape=None):
+        self.kind, self.coef, self.shape = kind, coef, shape
         self.plane_elem_size = [4 if kind == "jacobi" else 1]
+        if kind == "hotspot":  # two per-field planes (temp, power), as the HIP sweep of "hotspot" takes them
+            self.n_planes, self.plane_elem_size = 2, [4, 4]
         self.calls = []
 
     def __call__(self, src, dst, dom, out_begin, out_end, iteration, depth, stream):
@@ -43,6 +45,18 @@ class OracleSweep:
         g = depth * self.halo_per_generation
         need_lo, need_hi = max(0, out_begin - g), min(H, out_end + g)
         assert need_lo >= origin and need_hi <= origin + dom.local_rows, "sweep would read rows it does not hold"
+        if self.kind == "hotspot":
+            # the window's own top / bottom rows reflect like grid edges; that error travels one row per
+            # generation and never reaches the output rows, g rows away (at true grid edges it is exact)
+            cells = np.zeros((need_hi - need_lo, dom.global_width), dtype=O.HOTSPOT_CELL)
+            cells["temp"] = src[0].numpy().view(np.float32)[need_lo - origin:need_hi - origin]
+            cells["power"] = src[1].numpy().view(np.float32)[need_lo - origin:need_hi - origin]
+            out = self._hotspot_window(O, cells, need_lo, H, depth)
+            for plane, field in ((0, "temp"), (1, "power")):
+                dst[plane].numpy().view(np.float32)[out_begin - origin:out_end - origin] = \
+                    out[field][out_begin - need_lo:out_end - need_lo]
+            self.calls.append((out_begin, out_end, depth))
+            return
         buf = src[0].numpy().view(dt)
         sub = np.ascontiguousarray(buf[need_lo - origin:need_hi - origin])
         if self.kind == "jacobi":
@@ -51,6 +65,14 @@ class OracleSweep:
             out = O.conway(sub, depth)
         dst[0].numpy().view(dt)[out_begin - origin:out_end - origin] = out[out_begin - need_lo:out_end - need_lo]
         self.calls.append((out_begin, out_end, depth))
+
+
+    def _hotspot_window(self, O, cells, need_lo, H, depth):
+        """The constants come from the GLOBAL grid shape (hotspot.cpp:281-295); the oracle reflects at the first and
+        last row of whatever it is given, which is right where the window touches the global edge and lands on
+        rows nobody reads where it does not."""
+        p = O.hotspot_params(*self.shape)
+        return O.hotspot(p, cells, depth)
 
 
 def worker(rank, world, port, kind, H, W, gens, seed, result_dir, sub_strips=None):
@@ -66,18 +88,27 @@ def worker(rank, world, port, kind, H, W, gens, seed, result_dir, sub_strips=Non
     if kind == "jacobi":
         grid = rng.random((H, W), dtype=np.float32)
         sweep = OracleSweep("jacobi", [0.2, 0.21, 0.19, 0.22, 0.18])
+    elif kind == "hotspot":
+        grid = (320 + 10 * rng.random((H, W), dtype=np.float32)).astype(np.float32)
+        power = (rng.random((H, W), dtype=np.float32) * 0.01).astype(np.float32)
+        sweep = OracleSweep("hotspot", shape=(H, W))
     else:
         grid = (rng.random((H, W)) < 0.4).astype(np.uint8)
         sweep = OracleSweep("conway")
     strip = StripDomain(None, None, None, H, W, rank, world, "cpu", sweep=sweep, sub_strips=sub_strips)
     a, b = strip.row_begin, strip.row_end
-    strip.load_owned(torch.from_numpy(grid[a:b].copy()))
+    if kind == "hotspot":
+        strip.load_owned(torch.from_numpy(grid[a:b].copy()), torch.from_numpy(power[a:b].copy()))
+    else:
+        strip.load_owned(torch.from_numpy(grid[a:b].copy()))
     done = 0
     for chunk in gens:  # several advance() calls: resume semantics
         strip.advance(done, chunk)
         done += chunk
-    mine = strip.owned(0, torch.float32 if kind == "jacobi" else torch.uint8).numpy()
+    mine = strip.owned(0, torch.uint8 if kind == "conway" else torch.float32).numpy()
     np.save(os.path.join(result_dir, f"rank{rank}.npy"), mine)
+    if kind == "hotspot":  # the second plane travels with the first and comes back unchanged
+        assert np.array_equal(strip.owned(1, torch.float32).numpy(), power[a:b])
     # boundary bands must be swept before the interior in every pass: the first launch is a band
     # (at most one halo depth of rows) next to a neighbour
     first = sweep.calls[0]
@@ -105,7 +136,7 @@ def worker(rank, world, port, kind, H, W, gens, seed, result_dir, sub_strips=Non
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("kind,H,W,gens", [("jacobi", 97, 40, [7]), ("jacobi", 64, 33, [4, 4, 1]),
-                                           ("conway", 90, 50, [10])])
+                                           ("conway", 90, 50, [10]), ("hotspot", 84, 37, [9, 3])])
 def test_strips_equal_whole_grid(oracle, tmp_path, world, kind, H, W, gens):
     seed = 1234
     mp.spawn(worker, args=(world, free_port(), kind, H, W, gens, seed, str(tmp_path)), nprocs=world, join=True)
@@ -114,6 +145,11 @@ def test_strips_equal_whole_grid(oracle, tmp_path, world, kind, H, W, gens):
     if kind == "jacobi":
         grid = rng.random((H, W), dtype=np.float32)
         want = oracle.jacobi("Jacobi5General", [0.2, 0.21, 0.19, 0.22, 0.18], grid, total, halo=0.0)
+    elif kind == "hotspot":
+        cells = np.zeros((H, W), dtype=oracle.HOTSPOT_CELL)
+        cells["temp"] = (320 + 10 * rng.random((H, W), dtype=np.float32)).astype(np.float32)
+        cells["power"] = (rng.random((H, W), dtype=np.float32) * 0.01).astype(np.float32)
+        want = np.ascontiguousarray(oracle.hotspot(oracle.hotspot_params(H, W), cells, total)["temp"])
     else:
         grid = (rng.random((H, W)) < 0.4).astype(np.uint8)
         want = oracle.conway(grid, total)
