@@ -56,7 +56,7 @@ template <typename Cell> class Grid {
         void need_device() {
             if (!device) {
                 internal::ensure_runtime(-1);
-                device = internal::device_alloc(bytes());
+                device = internal::device_alloc_on(bytes(), internal::default_stream());
             }
         }
         void sync_to_host() {

@@ -182,7 +182,7 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
         Planes sets[2];
         for (auto &set : sets)
             for (int f = 0; f < n; f++)
-                set.plane[f] = internal::device_alloc(n_cells * sizes[f]);
+                set.plane[f] = internal::device_alloc_on(n_cells * sizes[f], stream);
 
         internal::check(ststhip_scatter_fields(source_grid.device_cells(), sizeof(Cell), n_cells, n,
                                                offsets, sizes, sets[0].plane, stream),
@@ -193,10 +193,11 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
                                               n_cells, n, offsets, sizes,
                                               const_cast<const void *const *>(sets[1].plane), stream),
                         "gather");
-        // pool blocks are recycled in stream order, so they can be returned while work is queued
+        // releases are ordered after the work queued on `stream` (ststhip_free_async), so the planes can be
+        // returned while the sweeps and the gather are still in flight
         for (auto &set : sets)
             for (int f = 0; f < n; f++)
-                ststhip_free(set.plane[f]);
+                ststhip_free_async(set.plane[f], stream);
         return result;
     }
 

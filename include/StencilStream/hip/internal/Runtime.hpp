@@ -38,6 +38,13 @@ inline void *device_alloc(std::size_t bytes) {
     return p;
 }
 
+// for work on `stream`: a pooled block released on another stream is waited for on `stream`, not by the host
+inline void *device_alloc_on(std::size_t bytes, ststhip_stream stream) {
+    void *p = nullptr;
+    check(ststhip_malloc_async(&p, bytes ? bytes : 1, stream), "ststhip_malloc_async");
+    return p;
+}
+
 inline void *pinned_alloc(std::size_t bytes) {
     void *p = nullptr;
     check(ststhip_host_malloc(&p, bytes ? bytes : 1), "ststhip_host_malloc");

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -729,9 +730,14 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     // 4 waves per workgroup: 2 or 1 are 1-3 % slower (profiles/r01_tune_taper.txt, last section)
     constexpr unsigned waves_per_block = 4;
     const void *kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd>);
-    static int resident_blocks = 0; // per kernel instantiation
-    if (resident_blocks == 0)
+    // per kernel instantiation; a property of the code object and the architecture, so racing host
+    // threads would store the same number
+    static std::atomic<int> resident_blocks_cache{0};
+    int resident_blocks = resident_blocks_cache.load(std::memory_order_relaxed);
+    if (resident_blocks == 0) {
         check(ststhip_occupancy(kernel, waves_per_block * wave_size, 0, &resident_blocks), "occupancy query");
+        resident_blocks_cache.store(resident_blocks, std::memory_order_relaxed);
+    }
     // per-field planes of fields F only copies: from the third pass of a run on the target holds them already
     if constexpr (SOA && constant_plane_mask<F>() != 0)
         if (ststhip_target_holds_constants() && env_int("STSTHIP_SKIP_CONSTANT_STORES", 1))

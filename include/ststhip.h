@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STSTHIP_ABI_VERSION 1
+#define STSTHIP_ABI_VERSION 2
 
 typedef enum {
     STSTHIP_OK = 0,
@@ -63,9 +63,16 @@ int ststhip_device_count(int *count);
 int ststhip_device_name(char *buf, size_t buf_size);
 int ststhip_compute_units(int *count);
 
-/* Device memory from a size-bucketed pool (freed blocks are reused, not returned to HIP). */
+/* Device memory from a size-bucketed pool (freed blocks are reused, not returned to HIP).
+ * Releases are stream-ordered: ststhip_free_async(ptr, stream) may be called while work that uses the
+ * block is still queued on `stream`; the block is handed out again to the same stream at once, to any
+ * other stream after a wait on the release event, and to ststhip_malloc (host order) once that event has
+ * completed.  ststhip_free(ptr) = ststhip_free_async(ptr, NULL): release ordered after the runtime's own
+ * stream.  A block that other streams still use must be released on a stream that was joined with them. */
 int ststhip_malloc(void **ptr, size_t bytes);
 int ststhip_free(void *ptr);
+int ststhip_malloc_async(void **ptr, size_t bytes, ststhip_stream stream);
+int ststhip_free_async(void *ptr, ststhip_stream stream);
 int ststhip_pool_trim(void);
 /* Pinned host memory for grids' host mirrors.  Freed blocks are kept for reuse (pinning is slow) up
  * to STSTHIP_HOST_CACHE_MIB (default 4096) MiB; ststhip_pool_trim releases them. */
@@ -157,7 +164,10 @@ typedef struct {
     uint32_t max_generations;    /* deepest temporal blocking compiled in                */
     uint32_t tdv_size;           /* 0 = no time-dependent value                          */
     uint32_t halo_depth_per_generation; /* ghost rows one generation consumes per side   */
-    uint32_t strip_width;        /* columns one wavefront produces at max_generations    */
+    uint32_t strip_width;        /* columns one wavefront (cooperative: one workgroup) produces at max_generations */
+    uint32_t cells_per_lane;     /* adjacent cells a lane holds per row (K)              */
+    uint32_t prefetch_rows;      /* rows loaded ahead of the pipeline (P)                */
+    uint32_t cooperative;        /* 1: the waves of a workgroup share their edge columns through LDS */
 } ststhip_app_info;
 
 int ststhip_app_count(void);

@@ -90,6 +90,23 @@ class use_fma_build:
         _LIB = self.saved
 
 
+class window:
+    """Context manager: the arrays handed to the oracle are the window at (row0, col0) of a grid_h x grid_w
+    grid; transition functions see global coordinates and the global grid range (stencil_oracle.c, window
+    mode).  Results are exact further than n * n_subiterations * radius cells from window borders that are
+    not borders of the grid."""
+
+    def __init__(self, row0, col0, grid_h, grid_w):
+        self.args = (row0, col0, grid_h, grid_w)
+
+    def __enter__(self):
+        lib().oracle_set_window(*[_sz(v) for v in self.args])
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_window(_sz(0), _sz(0), _sz(0), _sz(0))
+
+
 def cpu_has_fma():
     try:
         return " fma " in open("/proc/cpuinfo").read()

@@ -14,6 +14,19 @@
 #include <omp.h>
 #endif
 
+/* Window mode (tests of grids too large to sweep on the CPU): the buffers hold the window
+ * [row0, row0+H) x [col0, col0+W) of a larger grid; transition functions see the global coordinates and the
+ * global grid range, neighbours outside the WINDOW read the halo value.  Cells further than
+ * n_iterations * n_subiterations * radius from a window border that is not a border of the global grid are
+ * exact; the caller discards the rest.  Off (a whole grid) unless set. */
+static size_t window_row0 = 0, window_col0 = 0, window_grid_h = 0, window_grid_w = 0;
+void oracle_set_window(size_t row0, size_t col0, size_t grid_h, size_t grid_w) {
+    window_row0 = row0;
+    window_col0 = col0;
+    window_grid_h = grid_h;
+    window_grid_w = grid_w;
+}
+
 /* One full-grid sweep: StencilStream/cpu/StencilUpdate.hpp:185-223. */
 static void sweep(const oracle_function *f, const unsigned char *src, unsigned char *dst, size_t H,
                   size_t W, const unsigned char *halo, size_t iteration, size_t subiteration,
@@ -41,10 +54,10 @@ static void sweep(const oracle_function *f, const unsigned char *src, unsigned c
                 }
             }
             oracle_stencil st;
-            st.row = r;
-            st.col = c;
-            st.grid_h = H;
-            st.grid_w = W;
+            st.row = r + window_row0;
+            st.col = c + window_col0;
+            st.grid_h = window_grid_h ? window_grid_h : H;
+            st.grid_w = window_grid_w ? window_grid_w : W;
             st.iteration = iteration;
             st.subiteration = subiteration;
             st.tdv = tdv;
@@ -73,6 +86,10 @@ int oracle_run(const oracle_function *f, const void *in, void *out, size_t H, si
         free(tdv);
         return -1;
     }
+    /* touch the pages from one thread: first-touch faults taken by all OpenMP threads at once serialise on
+     * the address-space lock (seconds for a few hundred MiB inside a VM) */
+    memset(swap_a, 0, bytes);
+    memset(swap_b, 0, bytes);
     const unsigned char *pass_source = (const unsigned char *)in; /* :112 */
     unsigned char *pass_target = swap_b;                           /* :113 */
 

@@ -70,6 +70,10 @@ typedef struct {
  * allocation failure.  n_threads <= 1 runs scalar; otherwise OpenMP over rows
  * when compiled with -fopenmp.
  */
+/* Window mode for the next runs: buffers are the window at (row0, col0) of a grid_h x grid_w grid (see
+ * stencil_oracle.c); (0, 0, 0, 0) switches it off.  Process-wide, not thread-safe: tests only. */
+void oracle_set_window(size_t row0, size_t col0, size_t grid_h, size_t grid_w);
+
 int oracle_run(const oracle_function *f, const void *in, void *out, size_t H, size_t W,
                const void *halo_value, size_t iteration_offset, size_t n_iterations,
                int n_threads);

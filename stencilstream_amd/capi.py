@@ -56,6 +56,9 @@ class AppInfo(C.Structure):
         ("tdv_size", C.c_uint32),
         ("halo_depth_per_generation", C.c_uint32),
         ("strip_width", C.c_uint32),
+        ("cells_per_lane", C.c_uint32),
+        ("prefetch_rows", C.c_uint32),
+        ("cooperative", C.c_uint32),
     ]
 
 
@@ -142,6 +145,8 @@ def load():
         "ststhip_compute_units": [C.POINTER(C.c_int)],
         "ststhip_malloc": [pp, sz],
         "ststhip_free": [vp],
+        "ststhip_malloc_async": [pp, sz, vp],
+        "ststhip_free_async": [vp, vp],
         "ststhip_pool_trim": [],
         "ststhip_host_malloc": [pp, sz],
         "ststhip_host_free": [vp],

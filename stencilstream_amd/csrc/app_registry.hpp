@@ -79,6 +79,9 @@ template <typename F, bool SOA> struct AppAdapter {
         e.info.strip_width = std::uint32_t(
             stencil::hip::internal::Sweep<F, SOA, Tuning::max_generations, Tuning::cells_per_lane,
                                           Tuning::prefetch_rows, Tuning::interior_variant>::OW);
+        e.info.cells_per_lane = std::uint32_t(Tuning::cells_per_lane);
+        e.info.prefetch_rows = std::uint32_t(Tuning::prefetch_rows);
+        e.info.cooperative = 0;
         e.sweep = &sweep;
         return e;
     }

@@ -45,8 +45,15 @@ struct Runtime {
     int device = -1;
     int compute_units = 256;
     hipStream_t stream = nullptr;
-    // pool: bucket size -> free blocks; live: ptr -> bucket size
-    std::multimap<std::size_t, void *> free_blocks;
+    // pool: bucket size -> free blocks; live: ptr -> bucket size.  A free block remembers the stream it was
+    // released on and an event recorded there: work queued on that stream before the release may still use
+    // the block, so another stream (or the host) may only have it after the event.
+    struct FreeBlock {
+        void *ptr;
+        hipStream_t released_on;
+        hipEvent_t released; // nullptr: nothing in flight
+    };
+    std::multimap<std::size_t, FreeBlock> free_blocks;
     std::map<void *, std::size_t> live_blocks;
     // the same for pinned host memory (pinning hundreds of MiB costs tens of ms per allocation, and every
     // grid a StencilUpdate returns gets a host mirror as soon as the application looks at it)
@@ -63,10 +70,25 @@ static Runtime &rt() {
     return r;
 }
 
-// side streams of the pass driver (row strips advancing concurrently), created on demand
-static std::vector<hipStream_t> &side_streams() {
-    static std::vector<hipStream_t> streams;
+// Side streams of the pass driver (row strips advancing concurrently).  Every caller stream gets its own
+// set, created on demand under the runtime lock: two host threads (or two torch streams) that run the pass
+// driver side by side never share one.
+static std::map<hipStream_t, std::vector<hipStream_t>> &side_streams() {
+    static std::map<hipStream_t, std::vector<hipStream_t>> streams;
     return streams;
+}
+static bool side_streams_for(hipStream_t caller, int n, std::vector<hipStream_t> &out) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> guard(r.lock);
+    auto &pool = side_streams()[caller];
+    while (int(pool.size()) < n) {
+        hipStream_t extra;
+        if (hipStreamCreateWithFlags(&extra, hipStreamNonBlocking) != hipSuccess)
+            return false;
+        pool.push_back(extra);
+    }
+    out.assign(pool.begin(), pool.begin() + n);
+    return true;
 }
 
 static std::vector<AppEntry> &apps() {
@@ -81,6 +103,18 @@ const AppEntry *find_app(const char *name) {
         if (std::strcmp(e.info.name, name) == 0)
             return &e;
     return nullptr;
+}
+
+// hipFree of every pooled block, each after the work that was queued before its release
+static void release_free_blocks(Runtime &r) {
+    for (auto &kv : r.free_blocks) {
+        if (kv.second.released) {
+            (void)hipEventSynchronize(kv.second.released);
+            (void)hipEventDestroy(kv.second.released);
+        }
+        (void)hipFree(kv.second.ptr);
+    }
+    r.free_blocks.clear();
 }
 
 static hipStream_t resolve(ststhip_stream s) { return s ? static_cast<hipStream_t>(s) : rt().stream; }
@@ -300,14 +334,13 @@ int ststhip_shutdown(void) {
     if (!r.up)
         return STSTHIP_OK;
     (void)hipStreamSynchronize(r.stream);
-    for (hipStream_t extra : side_streams()) {
-        (void)hipStreamSynchronize(extra);
-        (void)hipStreamDestroy(extra);
-    }
+    for (auto &per_caller : side_streams())
+        for (hipStream_t extra : per_caller.second) {
+            (void)hipStreamSynchronize(extra);
+            (void)hipStreamDestroy(extra);
+        }
     side_streams().clear();
-    for (auto &kv : r.free_blocks)
-        (void)hipFree(kv.second);
-    r.free_blocks.clear();
+    release_free_blocks(r);
     for (auto &kv : r.free_host_blocks)
         (void)hipHostFree(kv.second);
     r.free_host_blocks.clear();
@@ -344,23 +377,59 @@ int ststhip_compute_units(int *count) {
     return STSTHIP_OK;
 }
 
-int ststhip_malloc(void **ptr, size_t bytes) {
+// Takes a free block of the bucket for use on `stream` (or by the host when for_host).  A block released on
+// the same stream is reusable at once (stream order); one released elsewhere makes `stream` wait for the
+// release event first (the host: blocks on it), unless the event has completed already.
+static int take_free_block(std::size_t bucket, hipStream_t stream, bool for_host, void **ptr) {
+    Runtime &r = rt();
+    Runtime::FreeBlock block{nullptr, nullptr, nullptr};
+    {
+        std::lock_guard<std::mutex> guard(r.lock);
+        auto range = r.free_blocks.equal_range(bucket);
+        auto pick = r.free_blocks.end();
+        for (auto it = range.first; it != range.second; ++it) {
+            Runtime::FreeBlock &b = it->second;
+            if (b.released && hipEventQuery(b.released) == hipSuccess) {
+                (void)hipEventDestroy(b.released);
+                b.released = nullptr;
+            }
+            if (!b.released || (!for_host && b.released_on == stream)) {
+                pick = it;
+                break;
+            }
+            if (pick == r.free_blocks.end())
+                pick = it;
+        }
+        if (pick == r.free_blocks.end())
+            return -1;
+        block = pick->second;
+        r.free_blocks.erase(pick);
+        r.live_blocks[block.ptr] = bucket;
+    }
+    if (block.released) {
+        hipError_t err = hipSuccess;
+        if (for_host)
+            err = hipEventSynchronize(block.released);
+        else if (block.released_on != stream)
+            err = hipStreamWaitEvent(stream, block.released, 0);
+        (void)hipEventDestroy(block.released);
+        if (err != hipSuccess)
+            return hip_fail(err, "waiting for a pooled block's release");
+    }
+    *ptr = block.ptr;
+    return STSTHIP_OK;
+}
+
+static int pool_malloc(void **ptr, size_t bytes, hipStream_t stream, bool for_host) {
     if (!ptr)
         return fail(STSTHIP_ERR_INVALID, "null argument");
     if (int rc = ststhip_init(-1))
         return rc;
     Runtime &r = rt();
     const std::size_t bucket = bucket_of(bytes ? bytes : 1);
-    {
-        std::lock_guard<std::mutex> guard(r.lock);
-        auto it = r.free_blocks.find(bucket);
-        if (it != r.free_blocks.end()) {
-            *ptr = it->second;
-            r.free_blocks.erase(it);
-            r.live_blocks[*ptr] = bucket;
-            return STSTHIP_OK;
-        }
-    }
+    const int taken = take_free_block(bucket, for_host ? nullptr : (stream ? stream : r.stream), for_host, ptr);
+    if (taken >= 0)
+        return taken;
     void *p = nullptr;
     hipError_t err = hipMalloc(&p, bucket);
     if (err != hipSuccess) {
@@ -375,7 +444,7 @@ int ststhip_malloc(void **ptr, size_t bytes) {
     return STSTHIP_OK;
 }
 
-int ststhip_free(void *ptr) {
+static int pool_free(void *ptr, hipStream_t stream) {
     if (!ptr)
         return STSTHIP_OK;
     Runtime &r = rt();
@@ -383,20 +452,36 @@ int ststhip_free(void *ptr) {
     auto it = r.live_blocks.find(ptr);
     if (it == r.live_blocks.end())
         return fail(STSTHIP_ERR_INVALID, "ststhip_free: pointer not from ststhip_malloc");
-    if (r.up)
-        r.free_blocks.emplace(it->second, ptr); // reused in stream order by later allocations
+    if (r.up) {
+        Runtime::FreeBlock block{ptr, stream ? stream : r.stream, nullptr};
+        // if the event cannot be made the block is simply kept out of circulation until the stream is idle
+        if (hipEventCreateWithFlags(&block.released, hipEventDisableTiming) == hipSuccess) {
+            if (hipEventRecord(block.released, block.released_on) != hipSuccess) {
+                (void)hipEventDestroy(block.released);
+                block.released = nullptr;
+                (void)hipStreamSynchronize(block.released_on);
+            }
+        } else {
+            block.released = nullptr;
+            (void)hipStreamSynchronize(block.released_on);
+        }
+        r.free_blocks.emplace(it->second, block);
+    }
     r.live_blocks.erase(it);
     return STSTHIP_OK;
 }
 
+int ststhip_malloc(void **ptr, size_t bytes) { return pool_malloc(ptr, bytes, nullptr, /*for_host=*/true); }
+int ststhip_malloc_async(void **ptr, size_t bytes, ststhip_stream stream) {
+    return pool_malloc(ptr, bytes, static_cast<hipStream_t>(stream), /*for_host=*/false);
+}
+int ststhip_free(void *ptr) { return pool_free(ptr, nullptr); }
+int ststhip_free_async(void *ptr, ststhip_stream stream) { return pool_free(ptr, static_cast<hipStream_t>(stream)); }
+
 int ststhip_pool_trim(void) {
     Runtime &r = rt();
     std::lock_guard<std::mutex> guard(r.lock);
-    if (r.up)
-        (void)hipStreamSynchronize(r.stream);
-    for (auto &kv : r.free_blocks)
-        (void)hipFree(kv.second);
-    r.free_blocks.clear();
+    release_free_blocks(r);
     for (auto &kv : r.free_host_blocks)
         (void)hipHostFree(kv.second);
     r.free_host_blocks.clear();
@@ -766,7 +851,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
     } else {
         if (depths.size() > 1)
             for (unsigned p = 0; p < n_planes && rc == STSTHIP_OK; p++)
-                rc = ststhip_malloc(&scratch[p], plane_cells * desc->plane_elem_size[p]);
+                rc = ststhip_malloc_async(&scratch[p], plane_cells * desc->plane_elem_size[p], s);
 
         auto new_event = [&]() {
             hipEvent_t e = nullptr;
@@ -777,23 +862,16 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         // streams of the strips: strip 0 runs on the caller's stream
         std::vector<hipStream_t> lane(strips, s);
         if (strips > 1 && rc == STSTHIP_OK) {
-            auto &pool = side_streams();
-            while (int(pool.size()) < strips - 1) {
-                hipStream_t extra;
-                if (hipStreamCreateWithFlags(&extra, hipStreamNonBlocking) != hipSuccess) {
-                    strips = 1;
-                    break;
-                }
-                pool.push_back(extra);
-            }
-            if (strips > 1) {
+            std::vector<hipStream_t> extra;
+            if (side_streams_for(s, strips - 1, extra)) {
                 hipEvent_t begin = new_event();
                 ordered(hipEventRecord(begin, s), "hipEventRecord");
                 for (int v = 1; v < strips; v++) {
-                    lane[v] = pool[v - 1];
+                    lane[v] = extra[v - 1];
                     ordered(hipStreamWaitEvent(lane[v], begin, 0), "hipStreamWaitEvent");
                 }
             } else {
+                strips = 1;
                 lane.assign(1, s);
             }
         }
@@ -874,9 +952,11 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         if (err != hipSuccess)
             rc = hip_fail(err, "hipStreamSynchronize");
     }
+    // released on the caller's stream, which every strip has been joined into above: the blocks go to
+    // another stream (or the host) only after the event recorded here -- also when a launch failed midway
     for (unsigned p = 0; p < n_planes; p++)
         if (scratch[p])
-            ststhip_free(scratch[p]); // recycled in stream order of the caller's stream (joined above)
+            ststhip_free_async(scratch[p], s);
     double kernel_s = 0.0;
     for (auto &ev : timed) {
         float ms = 0.0f;

@@ -179,6 +179,20 @@ class StripDomain:
         for rows, staged in landed:
             rows.copy_(staged, non_blocking=False)
 
+    def warm_up_exchange(self):
+        """One exchange of the deepest halo outside any timed region: RCCL sets up its point-to-point
+        channels on first use (tens of milliseconds).  Ghost rows are refreshed by every advance(), so
+        this changes nothing."""
+        if self.world == 1:
+            return
+        if self.on_gpu:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                self._exchange(self.planes[self.current], self.g_max)
+            self.comm_stream.synchronize()
+        else:
+            self._exchange(self.planes[self.current], self.g_max)
+
     def _peer(self, strip_rank):
         return strip_rank if self.group is None else dist.get_global_rank(self.group, strip_rank)
 

@@ -90,6 +90,10 @@ class Grid:
         array = np.ascontiguousarray(array)
         if array.shape != (self.height, self.width):
             raise ValueError("The target buffer has not the same size as the grid")
+        if self.cell_dtype == np.dtype("u1") and array.dtype != np.bool_ and array.size and int(array.max()) > 1:
+            # one-byte cells are the C++ `bool` cells of the Game of Life (examples/conway/conway.cpp:35):
+            # bytes 0 / 1 only.  The kernel on words of four cells relies on it (ststhip.h, ststhip_app_run)
+            raise ValueError("one-byte cells are C++ bools: every byte must be 0 or 1")
         raw = torch.from_numpy(array.view(np.uint8).reshape(-1).copy())
         if raw.numel():
             self.cells[: raw.numel()].copy_(raw)
