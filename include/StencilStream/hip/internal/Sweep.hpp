@@ -20,6 +20,13 @@
 //    inter-wave synchronisation); chunks overlap by G rows for pipeline warm-up.
 //  * HBM rows are read as one K-wide vector per lane (1 KiB per wave and row for fp32, K = 4),
 //    software-prefetched P rows ahead, and written the same way.
+//  * Cooperative strips (SweepTuning::cooperative, for transition functions that read no west / east
+//    neighbour in the southernmost stencil row): the four waves of a workgroup take four ADJACENT strips
+//    without overlap and hand each other the edge columns of every pipeline level through LDS, one
+//    workgroup barrier per row.  Only the workgroup as a whole overlaps its neighbours by G columns, so a
+//    wave produces (256*K - 2G)/4 instead of 64*K - 2G columns of the 64*K it loads and computes (FDTD:
+//    58 instead of 40 of 64).  This is the LDS halo exchange north_star asks for, placed where the
+//    redundancy was: replaces the per-work-item neighbour loads of cuda/StencilUpdate.hpp:346-396.
 #pragma once
 #include "../../Concepts.hpp"
 #include "../../Stencil.hpp"
@@ -199,6 +206,29 @@ template <int DppCtrl, typename T> STST_DEVICE inline T lane_shift(T const &valu
     __builtin_memcpy(&shifted, &words, sizeof(T));
     return shifted;
 }
+// The same shift, but the lane without a source lane (lane 0 for wave_shr, lane 63 for wave_shl) receives
+// `edge` instead (DPP with bound_ctrl = 0 leaves the destination, preloaded with `edge`, untouched there).
+template <int DppCtrl, typename T> STST_DEVICE inline T lane_shift_or(T const &value, T const &edge) {
+    static_assert(std::is_trivially_copyable_v<T>);
+    constexpr int n_words = int((sizeof(T) + 3) / 4);
+    struct Words {
+        int w[n_words];
+    } words = {}, old = {};
+    __builtin_memcpy(&words, &value, sizeof(T));
+    __builtin_memcpy(&old, &edge, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < n_words; i++)
+        words.w[i] = __builtin_amdgcn_update_dpp(old.w[i], words.w[i], DppCtrl, 0xf, 0xf, false);
+    T shifted;
+    __builtin_memcpy(&shifted, &words, sizeof(T));
+    return shifted;
+}
+template <typename T> STST_DEVICE inline T from_west_lane_or(T const &v, T const &edge) {
+    return lane_shift_or<0x138>(v, edge);
+}
+template <typename T> STST_DEVICE inline T from_east_lane_or(T const &v, T const &edge) {
+    return lane_shift_or<0x130>(v, edge);
+}
 // value of lane-1 (data moves towards higher lanes): DPP wave_shr:1
 template <typename T> STST_DEVICE inline T from_west_lane(T const &v) { return lane_shift<0x138>(v); }
 // value of lane+1: DPP wave_shl:1
@@ -232,6 +262,13 @@ template <typename Cell, bool SOA> constexpr int cell_words() {
 //   interior_variant     also build the check-free code path for waves away from the grid edge
 //   min_waves_per_simd   occupancy the register allocator must allow (second __launch_bounds__ argument)
 //   streaming_stores     (optional member) store results with the non-temporal hint (streaming_stores_for below)
+//   cooperative          (optional member, default false) the four waves of a workgroup take adjacent strips and
+//                        exchange their edge columns through LDS (see the head of Sweep.hpp).  ONLY for transition
+//                        functions that never read stencil[radius][dc] with dc != 0 ... more precisely: no cell of
+//                        the southernmost stencil row other than the columns of the lane's own cells, i.e. for
+//                        radius 1 neither stencil[1][-1] nor stencil[1][1] (5-point and "north-heavy" stencils).
+//                        The southernmost row is the one a level receives in the same step, before the
+//                        neighbour wave's copy can have crossed the barrier.
 //   trapezoid_fill       (optional member) skip the levels that are not due yet while a wave's pipeline fills;
 //                        default: cells of up to four words per generation (measured: Jacobi +3 %, HotSpot
 //                        +5 %, Conway +4 %, FDTD -2..-8 %: profiles/r01_ab_trapezoid_fill.txt)
@@ -306,6 +343,13 @@ struct SweepGeometry {
     std::uint32_t xcd_remap;            // 1: give every XCD a contiguous range of the wave grid
     std::uint32_t last_chunk_early;     // 1: the last row chunk is dispatched second instead of last
 };
+
+template <typename F, bool SOA> constexpr bool cooperative_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::cooperative; })
+        return SweepTuning<F, SOA>::cooperative;
+    else
+        return false;
+}
 
 template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
     if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })

@@ -124,7 +124,7 @@ def main():
             key = line["roofline"].get("kernel_key")
             break
     per_counter = {}
-    resources = None
+    by_shape_resources = {}
     for kind in ("fetch", "write", "sq"):
         f = newest(os.path.join(src, kind, "*", "*counter_collection.csv"))
         if not f:
@@ -135,12 +135,14 @@ def main():
                 continue
             shape = (r["Kernel_Name"][:170], grid_size(r))
             vals[r["Counter_Name"]][shape].append(float(r["Counter_Value"]))
-            if resources is None or grid_size(r) > resources[1]:
-                resources = ({k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
-                                                     "Scratch_Size", "Workgroup_Size", "Grid_Size")}, grid_size(r))
+            by_shape_resources[shape] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+                                                               "LDS_Block_Size", "Scratch_Size", "Workgroup_Size",
+                                                               "Grid_Size")}
+        depth = key.rsplit(":T", 1)[1] if key else ""
         for counter, by_shape in vals.items():
-            # full-grid launches of the roofline leg: the uniform middle-launch kernel with the largest grid
-            cand = [(s, v) for s, v in by_shape.items() if "Jacobi5Uniform<false, false>" in s[0]] or list(by_shape.items())
+            # full-grid launches of the roofline leg: the middle-launch kernel of the full depth with the largest grid
+            cand = [(s, v) for s, v in by_shape.items()
+                    if "Jacobi5Uniform<false, false>, false, " + depth + "," in s[0]] or list(by_shape.items())
             shape, v = max(cand, key=lambda sv: sv[0][1])
             per_counter[counter] = {"mean": sum(v) / len(v), "n": len(v), "kernel": shape[0], "grid_size": shape[1]}
     counters = {"tag": tag, "kernels": {}}
@@ -151,7 +153,7 @@ def main():
             "FETCH_SIZE_KiB_raw": fetch["mean"], "WRITE_SIZE_KiB_raw": write["mean"],
             "hbm_read_bytes": 2 * fetch["mean"] * 1024, "hbm_write_bytes": write["mean"] * 1024,
             "hbm_bytes_per_launch": 2 * fetch["mean"] * 1024 + write["mean"] * 1024,
-            "resources": resources[0] if resources else None,
+            "resources": by_shape_resources.get((fetch["kernel"], fetch["grid_size"])),
             "source": f"profiles/{tag}_counters.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU in separate "
                       "passes over `python3 bench.py --gpus 1 --steps 2 --warmup 1`; KiB units; FETCH_SIZE doubled "
                       "(gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); full-grid launches only",
