@@ -261,12 +261,47 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
-        strip = StripDomain(app, p, halo, total_rows, W, rank, world, device, np.dtype("<f4"),
-                            exchange_via_host=args.debug_host_exchange)
+        # Ghost rows: the native strip driver of libststhip.so (ststhip_strip_advance: RCCL send/recv issued from
+        # C++, no Python between the launches of a step).  If its communicator cannot be created on this node the
+        # run falls back -- on every rank alike -- to the same algorithm driven from Python over torch.distributed's
+        # RCCL point-to-point operations (stencilstream_amd/dist.py); the JSON line says which one ran.
+        native = not args.debug_host_exchange and os.environ.get("STSTHIP_BENCH_EXCHANGE", "native") == "native"
+        comm, why = None, None
+        if native and world > 1:
+            try:
+                uid = [capi.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = capi.comm_create(uid[0], rank, world)
+            except Exception as e:  # noqa: BLE001
+                why = f"{type(e).__name__}: {e}"
+            flag = torch.tensor([0 if comm is None else 1], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native = bool(flag.item())
         a, b = split_rows(total_rows, world)[rank]
-        strip.load_owned(init_grid_device(torch, b - a, W, a, total_rows, device))
+        init = init_grid_device(torch, b - a, W, a, total_rows, device)
+        if native:
+            strip = capi.Strip(app, p, halo, total_rows, W, rank, world, comm=comm)
+            assert (strip.row_begin, strip.row_end) == (a, b)
+            torch.cuda.synchronize()
+            strip.upload_from_device(0, init.data_ptr(), init.numel() * init.element_size())
+            strip.synchronize()
+            exchange = "RCCL send/recv issued by libststhip.so (ststhip_strip_advance)"
+
+            def step():
+                strip.advance(0, gens)
+        else:
+            strip = StripDomain(app, p, halo, total_rows, W, rank, world, device, np.dtype("<f4"),
+                                exchange_via_host=args.debug_host_exchange)
+            strip.load_owned(init)
+            exchange = "torch.distributed batch_isend_irecv (stencilstream_amd/dist.py)" + (f"; native: {why}" if why else "")
+
+            def step():
+                strip.advance(0, gens)
         if world > 1:
-            strip.warm_up_exchange()  # RCCL creates its p2p channels on first use: outside the timed region
+            if native:
+                strip.warm_up()  # RCCL creates its p2p channels on first use: outside the timed region
+            else:
+                strip.warm_up_exchange()
             # what the driver can check the launch against: ranks, devices, RCCL
             mine = {"rank": rank, "device": torch.cuda.get_device_name(device), "local_rank": local_rank,
                     "rows": [a, b]}
@@ -275,13 +310,10 @@ def main():
             ranks_report = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                             "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version())
                             if not args.debug_host_exchange else None,
-                            "ranks": gathered}
-
-        def step():
-            strip.advance(0, gens)
+                            "ghost_exchange": exchange, "ranks": gathered}
 
         barrier = dist.barrier if world > 1 else (lambda: None)
-        decomposition = f"{world} row strips of {total_rows // world} rows, RCCL ghost rows once per launch"
+        decomposition = f"{world} row strips of {total_rows // world} rows, RCCL ghost rows once per launch; {exchange}"
 
     for _ in range(args.warmup):
         step()

@@ -137,10 +137,7 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
         desc.n_planes = Planes::n_planes;
         desc.max_generations = SweepTuning<F, on_planes>::max_generations;
         desc.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
-        using Tuning = SweepTuning<F, on_planes>;
-        desc.strip_width = std::uint32_t(
-            internal::Sweep<F, on_planes, Tuning::max_generations, Tuning::cells_per_lane,
-                            Tuning::prefetch_rows, Tuning::interior_variant>::OW);
+        desc.strip_width = std::uint32_t(internal::SweepOf<F, on_planes>::OW_PER_WAVE);
         for (int f = 0; f < Planes::n_planes; f++)
             desc.plane_elem_size[f] = Planes::elem_size(f);
         ststhip_run_info info = {};

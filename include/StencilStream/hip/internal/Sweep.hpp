@@ -351,6 +351,13 @@ template <typename F, bool SOA> constexpr bool cooperative_for() {
         return false;
 }
 
+template <typename F, bool SOA> constexpr int cooperative_debug_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::cooperative_debug; })
+        return SweepTuning<F, SOA>::cooperative_debug;
+    else
+        return 0;
+}
+
 template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
     if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })
         return SweepTuning<F, SOA>::trapezoid_fill;
@@ -395,7 +402,10 @@ template <typename F, bool SOA> constexpr bool streaming_stores_for() {
                cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 2;
 }
 
-template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> struct Sweep {
+constexpr int waves_per_block = 4; // 4 waves per workgroup: 2 or 1 are 1-3 % slower (profiles/r01_tune_taper.txt)
+
+// COOP_DEBUG (timing experiments only, results are wrong): 1 = no barrier, 2 = no LDS traffic, 3 = neither
+template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT, bool COOP = false, int COOP_DEBUG = 0> struct Sweep {
     using Cell = typename F::Cell;
     using TDV = typename F::TimeDependentValue;
     using Planes = PlaneSet<Cell, SOA>;
@@ -407,12 +417,25 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
     static constexpr int G = R * S;             // halo depth in cells (rows and columns)
     static constexpr int GX = round_up(G, K);   // column halo rounded to whole lanes
     static constexpr int LW = wave_size * K;    // columns a wave loads
-    static constexpr int OW = LW - 2 * GX;      // columns a wave produces
+    // columns one unit of the wave grid loads / produces: a wave, or (COOP) the waves of a workgroup
+    static constexpr int UW = COOP ? waves_per_block * LW : LW;
+    static constexpr int OW = UW - 2 * GX;
+    static constexpr int OW_PER_WAVE = COOP ? OW / waves_per_block : OW; // what the launch heuristics count waves with
     static constexpr int NWIN = 2 * R;          // rows each level keeps
     static constexpr int D = 2 * R + 1;
 
+    // COOP: edge columns in LDS.  Slot (step mod N_SLOTS) holds, per level and wave, the R westernmost cells of
+    // lane 0 and the R easternmost cells of lane 63 of the row that entered that level's window in that step.
+    static constexpr int CW = int((sizeof(Cell) + 3) / 4);          // 32-bit words per cell
+    static constexpr int N_SLOTS = 2 * R + 1;                       // rows alive in a window + the one being written
+    static constexpr int EDGE_WORDS = R * CW;                       // one edge of one wave at one level
+    static constexpr int LEVEL_WORDS = waves_per_block * 2 * EDGE_WORDS;
+    static constexpr int SLOT_WORDS = S * LEVEL_WORDS;
+    static constexpr int LDS_WORDS = COOP ? N_SLOTS * SLOT_WORDS : 1;
+
     static_assert(K >= R, "a lane must hold at least `radius` cells so neighbours are one lane away");
     static_assert(OW >= K, "halo consumes the whole strip: lower max_generations or raise K");
+    static_assert(!COOP || LDS_WORDS * 4 <= 64 * 1024, "edge exchange buffers exceed the LDS budget of a workgroup");
     static_assert(P % NWIN == 0, "prefetch depth must be a multiple of the window length");
     static_assert(std::is_trivially_copyable_v<F> && std::is_trivially_copyable_v<Cell> &&
                   std::is_trivially_copyable_v<TDV>);
@@ -427,12 +450,14 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
 
     // SKIP_CONSTANTS: the target planes of F::constant_fields already hold their values (see
     // constant_plane_mask); their stores are left out
+    // `strip`: index of the unit (wave, or workgroup if COOP) along the columns; `wib`: wave in the workgroup
     template <bool EDGE, bool SKIP_CONSTANTS>
     STST_DEVICE static void run(Args const &a, const int lane, const int strip, const int ya,
-                                const int yb) {
+                                const int yb, const int wib, std::uint32_t *lds) {
         constexpr std::uint32_t skip_mask = SKIP_CONSTANTS ? constant_plane_mask<F>() : 0u;
         SweepGeometry const &g = a.geo;
-        const int x0 = strip * OW - GX + lane * K; // global column of the lane's first cell
+        const int unit_x = COOP ? wib * LW + lane * K : lane * K; // column of the lane inside its unit
+        const int x0 = strip * OW - GX + unit_x; // global column of the lane's first cell
         const int ystart = ya - G;
         const int y_load_end = yb + G < g.load_hi ? yb + G : g.load_hi;
 
@@ -441,7 +466,28 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
         for (int k = 0; k < K; k++)
             col_in[k] = unsigned(x0 + k) < unsigned(g.grid_w);
         const bool vec_in = x0 >= 0 && x0 + K <= g.grid_w;
-        const bool lane_stores = lane * K >= GX && lane * K + K <= LW - GX;
+        const bool lane_stores = unit_x >= GX && unit_x + K <= UW - GX;
+
+        // COOP: LDS word offsets.  A lane reads the neighbour waves' edges (every lane the same address; only the
+        // value of lane 0 / 63 is used) and the two edge lanes write their own.
+        int lds_west = 0, lds_east = 0, lds_mine = 0; // words inside a (slot, level) block
+        if constexpr (COOP) {
+            const int w_west = wib > 0 ? wib - 1 : 0, w_east = wib + 1 < waves_per_block ? wib + 1 : wib;
+            lds_west = (w_west * 2 + 1) * EDGE_WORDS; // east edge of the wave to the west
+            lds_east = (w_east * 2 + 0) * EDGE_WORDS; // west edge of the wave to the east
+            lds_mine = (wib * 2 + (lane == 0 ? 0 : 1)) * EDGE_WORDS;
+        }
+        int slot_now = 0; // slot written in this step; the row of m steps ago is in slot (slot_now - m) mod N_SLOTS
+        auto lds_cell = [&](int slot, int level_index, int edge_offset, int e) __attribute__((always_inline)) {
+            Cell cell;
+            std::uint32_t words[CW] = {};
+            const std::uint32_t *from = lds + slot * SLOT_WORDS + level_index * LEVEL_WORDS + edge_offset + e * CW;
+#pragma unroll
+            for (int i = 0; i < CW; i++)
+                words[i] = from[i];
+            __builtin_memcpy(&cell, words, sizeof(Cell));
+            return cell;
+        };
 
         Cell win[S][NWIN][K]; // level l-1's older rows, rotating
         Cell pre[P][K];       // rows in flight from HBM
@@ -506,6 +552,26 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                             cur[k] = a.halo;
                 }
 
+                // COOP: the neighbour waves' edge cells of the window rows of every level, fetched before this
+                // step writes anything to LDS (so the reads are not ordered behind those writes and their
+                // latency is paid once per row, not once per level); what the transition function does not
+                // use is never loaded.  Window row rr entered D-1-rr steps ago and has crossed a barrier since.
+                Cell edge_west[COOP ? S : 1][D - 1][R], edge_east[COOP ? S : 1][D - 1][R];
+                if constexpr (COOP && !(COOP_DEBUG & 2)) {
+                    static_for<0, S>([&](auto lc) __attribute__((always_inline)) {
+                        static_for<0, D - 1>([&](auto rr) __attribute__((always_inline)) {
+                            constexpr int age = D - 1 - int(rr);
+                            int slot = slot_now - age;
+                            slot = slot < 0 ? slot + N_SLOTS : slot;
+#pragma unroll
+                            for (int e = 0; e < R; e++) {
+                                edge_west[lc][rr][e] = lds_cell(slot, lc, lds_west, e);
+                                edge_east[lc][rr][e] = lds_cell(slot, lc, lds_east, e);
+                            }
+                        });
+                    });
+                }
+
                 bool live = true; // FILLING: the levels up to here are due at this row
                 static_for<0, S>([&](auto lc) __attribute__((always_inline)) {
                     constexpr int level = lc + 1;           // level being computed
@@ -539,10 +605,18 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
 #pragma unroll
                         for (int k = 0; k < K; k++)
                             ext[rr][R + k] = row[k];
+                        if constexpr (COOP && !(COOP_DEBUG & 2) && rr < D - 1) {
 #pragma unroll
-                        for (int d = 1; d <= R; d++) {
-                            ext[rr][R - d] = from_west_lane(row[K - d]);
-                            ext[rr][R + K - 1 + d] = from_east_lane(row[d - 1]);
+                            for (int d = 1; d <= R; d++) {
+                                ext[rr][R - d] = from_west_lane_or(row[K - d], edge_west[lc][rr][R - d]);
+                                ext[rr][R + K - 1 + d] = from_east_lane_or(row[d - 1], edge_east[lc][rr][d - 1]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int d = 1; d <= R; d++) {
+                                ext[rr][R - d] = from_west_lane(row[K - d]);
+                                ext[rr][R + K - 1 + d] = from_east_lane(row[d - 1]);
+                            }
                         }
                     });
 
@@ -598,6 +672,35 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
                                 a.dst.template store_one<skip_mask>(first + k, cur[k]);
                     }
                 }
+                if constexpr (COOP) {
+                    // The rows that entered the windows in this step now sit in the windows' `oldest` slots (they
+                    // replaced the oldest rows): their edge cells go to the neighbour waves.  One masked block per
+                    // step -- a branch per level would cut the step into basic blocks too small for the scheduler
+                    // to interleave the levels.
+                    if ((lane == 0 || lane == wave_size - 1) && !(COOP_DEBUG & 2)) {
+                        static_for<0, S>([&](auto lc) __attribute__((always_inline)) {
+                            constexpr int entered = u % NWIN;
+                            std::uint32_t *to = lds + slot_now * SLOT_WORDS + lc * LEVEL_WORDS + lds_mine;
+#pragma unroll
+                            for (int e = 0; e < R; e++) {
+                                Cell const &cell = lane == 0 ? win[lc][entered][e] : win[lc][entered][K - R + e];
+                                std::uint32_t words[CW] = {};
+                                __builtin_memcpy(words, &cell, sizeof(Cell));
+#pragma unroll
+                                for (int i = 0; i < CW; i++)
+                                    to[e * CW + i] = words[i];
+                            }
+                        });
+                    }
+                    // edges of this step become visible to the other waves; LDS only -- the rows in flight from
+                    // HBM (pre[]) must not be waited for here
+                    if constexpr (!(COOP_DEBUG & 1)) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                    }
+                    slot_now = slot_now + 1 == N_SLOTS ? 0 : slot_now + 1;
+                }
         };
 
         // Waves at the grid edge are few: they keep one loop (every level at every row) and small code.
@@ -610,9 +713,10 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
             static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, it, std::false_type{}); });
     }
 
-    template <bool SKIP_CONSTANTS = false> STST_DEVICE static void entry(Args const &a) {
+    template <bool SKIP_CONSTANTS = false> STST_DEVICE static void entry(Args const &a, std::uint32_t *lds) {
         SweepGeometry const &g = a.geo;
         const int lane = int(threadIdx.x) & (wave_size - 1);
+        const int wib = int(__builtin_amdgcn_readfirstlane(threadIdx.x / wave_size));
         // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, each with its own
         // L2).  Renumber them so that the blocks of one XCD cover a contiguous range of (strip, chunk)
         // tiles: neighbouring tiles share halo columns/rows, which then hit in that XCD's L2.  Only the
@@ -623,14 +727,15 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
             const unsigned q = gridDim.x / n_xcd, r = gridDim.x % n_xcd, x = block % n_xcd;
             block = x * q + (x < r ? x : r) + block / n_xcd;
         }
-        const unsigned wave =
-            __builtin_amdgcn_readfirstlane(block * (blockDim.x / wave_size) + threadIdx.x / wave_size);
-        if (wave >= g.n_strips * g.n_chunks)
+        // unit of the wave grid: a wave, or (COOP) the whole workgroup -- its waves then share strip and chunk,
+        // run the same number of rows and meet at one barrier per row
+        const unsigned unit = COOP ? block : __builtin_amdgcn_readfirstlane(block * unsigned(waves_per_block) + unsigned(wib));
+        if (unit >= g.n_strips * g.n_chunks)
             return;
-        const int strip = int(wave % g.n_strips);
+        const int strip = int(unit % g.n_strips);
         // The bottom chunk of a launch that reaches the grid's last rows runs the slower edge code; in
         // dispatch order it would come last and stretch the end of the launch, so it is moved to the front.
-        int chunk = int(wave / g.n_strips);
+        int chunk = int(unit / g.n_strips);
         if (g.last_chunk_early && g.n_chunks >= 3)
             chunk = chunk == 0 ? 0 : (chunk == 1 ? int(g.n_chunks) - 1 : chunk - 1);
         int tier = 0;
@@ -643,23 +748,29 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT> stru
         yb = yb < g.out_end ? yb : g.out_end;
 
         if constexpr (INTERIOR_VARIANT) {
-            const int xw0 = strip * OW - GX;
+            const int xw0 = strip * OW - GX; // footprint of the unit: decided per workgroup when COOP
             const bool interior =
-                xw0 >= 0 && xw0 + LW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
+                xw0 >= 0 && xw0 + UW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
             if (interior)
-                run<false, SKIP_CONSTANTS>(a, lane, strip, ya, yb);
+                run<false, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds);
             else
-                run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb);
+                run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds);
         } else {
-            run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb);
+            run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds);
         }
     }
 };
 
+// The sweep SweepTuning<F, SOA> asks for, at blocking depth T.
+template <typename F, bool SOA, int T = SweepTuning<F, SOA>::max_generations>
+using SweepOf = Sweep<F, SOA, T, SweepTuning<F, SOA>::cells_per_lane, SweepTuning<F, SOA>::prefetch_rows,
+                      SweepTuning<F, SOA>::interior_variant, cooperative_for<F, SOA>(), cooperative_debug_for<F, SOA>()>;
+
 // MIN_WAVES = waves per SIMD the register allocator must leave room for (launch-bounds semantics).
 template <typename SW, int MIN_WAVES = 1, bool SKIP_CONSTANTS = false>
 __global__ void __launch_bounds__(256, MIN_WAVES) sweep_kernel(const typename SW::Args args) {
-    SW::template entry<SKIP_CONSTANTS>(args);
+    __shared__ std::uint32_t edge_columns[SW::LDS_WORDS]; // cooperative strips only (one word otherwise)
+    SW::template entry<SKIP_CONSTANTS>(args, edge_columns);
 }
 
 // ------------------------------------------------------------------ host side
@@ -755,8 +866,8 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
                   PlaneSet<typename F::Cell, SOA> const &dst, std::uint64_t out_begin,
                   std::uint64_t out_end, std::uint64_t iteration, ststhip_stream stream) {
     using Tuning = SweepTuning<F, SOA>;
-    using SW = Sweep<F, SOA, T, Tuning::cells_per_lane, Tuning::prefetch_rows,
-                     Tuning::interior_variant>;
+    using SW = SweepOf<F, SOA, T>;
+    constexpr bool coop = cooperative_for<F, SOA>();
     if (out_end <= out_begin || dom.global_width == 0)
         return;
     if (dom.global_height >= (1ull << 31) || dom.global_width >= (1ull << 31))
@@ -771,8 +882,6 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
                                                     dom.row_origin + std::int64_t(dom.local_rows)));
     g.out_begin = std::int32_t(out_begin);
     g.out_end = std::int32_t(out_end);
-    // 4 waves per workgroup: 2 or 1 are 1-3 % slower (profiles/r01_tune_taper.txt, last section)
-    constexpr unsigned waves_per_block = 4;
     const void *kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd>);
     // per kernel instantiation; a property of the code object and the architecture, so racing host
     // threads would store the same number
@@ -786,9 +895,9 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     if constexpr (SOA && constant_plane_mask<F>() != 0)
         if (ststhip_target_holds_constants() && env_int("STSTHIP_SKIP_CONSTANT_STORES", 1))
             kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, true>);
-    g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW);
-    g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), g.n_strips, SW::G, resident_blocks,
-                                   int(waves_per_block));
+    g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW); // units: waves, or workgroups (coop)
+    g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), coop ? g.n_strips * waves_per_block : g.n_strips,
+                                   SW::G, resident_blocks, int(waves_per_block));
     g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
     plan_tiers(g, int(out_end - out_begin));
     g.pitch = dom.pitch;
@@ -803,8 +912,8 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         return typename SW::Args{f, halo, {tdv[Is]...}, src, dst, g};
     }(std::make_index_sequence<std::size_t(T)>{});
 
-    const unsigned waves = g.n_strips * g.n_chunks;
-    const unsigned blocks = (waves + waves_per_block - 1) / waves_per_block;
+    const unsigned units = g.n_strips * g.n_chunks;
+    const unsigned blocks = coop ? units : (units + waves_per_block - 1) / waves_per_block;
     void *kernel_args[] = {&args};
     check(ststhip_launch(kernel, blocks, 1, 1,
                          waves_per_block * wave_size, 1, 1, kernel_args, 0, stream),

@@ -137,6 +137,25 @@ int ststhip_gather_fields(void *aos, size_t cell_size, size_t n_cells, int n_fie
                           const size_t *field_offset, const size_t *field_size,
                           const void *const *planes, ststhip_stream stream);
 
+/* Device-side maximum of |field| over a sub-rectangle of an AoS grid, for up to 8 fields in ONE pass over the
+ * cells: what an application's convergence check needs from a grid without bringing the cells to the host
+ * (replaces the host scan of examples/convection/convection.cpp:412-438; an extension -- the reference's API has
+ * no reduction).  Field i is the f32 / f64 at byte `offset` of every cell; only cells with row < row_limit and
+ * column < col_limit count.  result[i] = max |value| (NaNs are skipped, as `std::abs(v) > max` skips them), or
+ * -infinity when no cell counts.  Wave-level DPP reduction, one atomic per wave and field.  Synchronises
+ * `stream` and writes `result` (host memory) before returning. */
+#define STSTHIP_F32 0u
+#define STSTHIP_F64 1u
+typedef struct {
+    uint32_t offset;
+    uint32_t type; /* STSTHIP_F32 or STSTHIP_F64 */
+    uint64_t row_limit;
+    uint64_t col_limit;
+} ststhip_reduce_field;
+int ststhip_reduce_max_abs(const void *cells, size_t cell_size, uint64_t height, uint64_t width,
+                           uint64_t pitch, int n_fields, const ststhip_reduce_field *fields,
+                           double *result, ststhip_stream stream);
+
 /* ------------------------------------------------------------- layer 1 */
 
 /* Where a buffer sits inside the global grid.  A single-GPU grid has row_origin = 0 and
@@ -164,7 +183,7 @@ typedef struct {
     uint32_t max_generations;    /* deepest temporal blocking compiled in                */
     uint32_t tdv_size;           /* 0 = no time-dependent value                          */
     uint32_t halo_depth_per_generation; /* ghost rows one generation consumes per side   */
-    uint32_t strip_width;        /* columns one wavefront (cooperative: one workgroup) produces at max_generations */
+    uint32_t strip_width;        /* columns one wavefront produces at max_generations (cooperative: a quarter of its workgroup's) */
     uint32_t cells_per_lane;     /* adjacent cells a lane holds per row (K)              */
     uint32_t prefetch_rows;      /* rows loaded ahead of the pipeline (P)                */
     uint32_t cooperative;        /* 1: the waves of a workgroup share their edge columns through LDS */
@@ -267,6 +286,43 @@ int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *cons
                                const void *const *send_down, void *const *recv_up,
                                void *const *recv_down, const size_t *row_bytes, size_t n_rows,
                                ststhip_stream stream);
+
+/* ------------------------------------------------- row-strip driver (one strip per process / GPU)
+ * The grid is cut into n_ranks strips of consecutive rows; every process owns one strip on its GPU and keeps it,
+ * with ghost rows, in two buffer sets inside the library.  ststhip_strip_advance() is cuda::StencilUpdate::operator()
+ * for the whole distributed grid: per launch of T generations it sweeps the boundary bands first, exchanges the
+ * T*radius*n_subiterations ghost rows of the NEXT launch with the two neighbours on a second stream (RCCL
+ * send/recv over xGMI, no collective) while the interiors run, and splits the owned rows into two sub-strips on
+ * two streams like the single-GPU pass driver.  No host code between the launches of a call: a C++ (or any FFI)
+ * host calls create / upload / advance / download.  The semantics are those of one StencilUpdate on the whole
+ * grid (the reference has no spatial decomposition; role model for "same interface, several devices":
+ * StencilStream/monotile/StencilUpdate.hpp:166-227).
+ *
+ * `comm`: a communicator of exactly the n_ranks strips (ststhip_comm_create), rank r = strip r.  Hosts whose ranks
+ * cannot be joined by RCCL (tests: several ranks on one GPU) pass comm = NULL and an `exchange` callback with the
+ * contract of ststhip_comm_exchange_rows: it must have filled recv_up / recv_down in stream order of `stream`
+ * (a callback that stages through host memory synchronises `stream` itself). */
+typedef void *ststhip_strip;
+typedef int (*ststhip_exchange_fn)(void *ctx, int n_planes, const void *const *send_up,
+                                   const void *const *send_down, void *const *recv_up,
+                                   void *const *recv_down, const size_t *row_bytes, size_t n_rows,
+                                   ststhip_stream stream);
+int ststhip_strip_create(const char *app, const void *tf_params, const void *halo_cell, uint64_t total_rows,
+                         uint64_t width, int rank, int n_ranks, ststhip_comm comm, ststhip_exchange_fn exchange,
+                         void *exchange_ctx, ststhip_strip *strip);
+int ststhip_strip_destroy(ststhip_strip strip);
+/* global rows [row_begin, row_end) this strip owns */
+int ststhip_strip_rows(ststhip_strip strip, uint64_t *row_begin, uint64_t *row_end);
+/* Device pointer to the first owned row of plane `plane` of the CURRENT buffer set (it changes with every
+ * advance) and the bytes per row; rows are dense.  Upload / download with ststhip_memcpy_* on the strip's stream. */
+int ststhip_strip_plane(ststhip_strip strip, unsigned plane, void **owned_rows, size_t *row_bytes);
+int ststhip_strip_stream(ststhip_strip strip, ststhip_stream *stream);
+int ststhip_strip_synchronize(ststhip_strip strip);
+/* One ghost exchange outside any timed region (RCCL sets up its channels on first use). */
+int ststhip_strip_warm_up(ststhip_strip strip);
+/* Advance the whole distributed grid by n_generations generations (every rank calls it with the same arguments). */
+int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64_t n_generations, int blocking);
+int ststhip_strip_counters(ststhip_strip strip, uint64_t *n_launches, uint64_t *n_exchanges);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,12 @@ class FdtdParams(C.Structure):
     ]
 
 
+class ReduceField(C.Structure):
+    """ststhip_reduce_field"""
+
+    _fields_ = [("offset", C.c_uint32), ("type", C.c_uint32), ("row_limit", C.c_uint64), ("col_limit", C.c_uint64)]
+
+
 class NoParams(C.Structure):
     _fields_ = [("unused", C.c_int)]
 
@@ -172,6 +178,7 @@ def load():
         "ststhip_suggest_row_strips": [C.c_char_p, u64, u64, u64],
         "ststhip_scatter_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
         "ststhip_gather_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
+        "ststhip_reduce_max_abs": [vp, sz, u64, u64, u64, C.c_int, C.POINTER(ReduceField), C.POINTER(C.c_double), vp],
         "ststhip_app_count": [],
         "ststhip_app_info_at": [C.c_int, C.POINTER(AppInfo)],
         "ststhip_app_find": [C.c_char_p, C.POINTER(AppInfo)],
@@ -184,6 +191,15 @@ def load():
         "ststhip_comm_create": [C.c_char_p, C.c_int, C.c_int, pp],
         "ststhip_comm_destroy": [vp],
         "ststhip_comm_exchange_rows": [vp, C.c_int, pp, pp, pp, pp, C.POINTER(sz), sz, vp],
+        "ststhip_strip_create": [C.c_char_p, vp, vp, u64, u64, C.c_int, C.c_int, vp, vp, vp, pp],
+        "ststhip_strip_destroy": [vp],
+        "ststhip_strip_rows": [vp, C.POINTER(u64), C.POINTER(u64)],
+        "ststhip_strip_plane": [vp, C.c_uint, pp, C.POINTER(sz)],
+        "ststhip_strip_stream": [vp, pp],
+        "ststhip_strip_synchronize": [vp],
+        "ststhip_strip_warm_up": [vp],
+        "ststhip_strip_advance": [vp, u64, u64, C.c_int],
+        "ststhip_strip_counters": [vp, C.POINTER(u64), C.POINTER(u64)],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared entry point
@@ -307,6 +323,131 @@ def set_launch_concurrency(n):
 def suggest_row_strips(app, rows, width, n_passes):
     """1 or 2: row strips (on separate streams) the pass driver would use for such a grid."""
     return int(load().ststhip_suggest_row_strips(app.encode(), int(rows), int(width), int(n_passes)))
+
+
+def reduce_max_abs(cells_ptr, cell_size, height, width, fields, pitch=None, stream=0):
+    """max |field| over row < row_limit, column < col_limit for every (offset, 'f4'|'f8', row_limit, col_limit)
+    of `fields`, in one pass on the device; -inf where no cell counts."""
+    n = len(fields)
+    table = (ReduceField * n)(*[ReduceField(int(o), 1 if str(t) in ("f8", "<f8", "float64") else 0, int(r), int(c))
+                                for o, t, r, c in fields])
+    result = (C.c_double * n)()
+    check(load().ststhip_reduce_max_abs(C.c_void_p(int(cells_ptr)), cell_size, height, width,
+                                        width if pitch is None else pitch, n, table, result,
+                                        C.c_void_p(int(stream))), "ststhip_reduce_max_abs")
+    return list(result)
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_void_p)
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(load().ststhip_comm_unique_id(buf), "ststhip_comm_unique_id")
+    return buf.raw
+
+
+def comm_create(unique_id, rank, n_ranks):
+    comm = C.c_void_p()
+    check(load().ststhip_comm_create(C.create_string_buffer(unique_id, COMM_ID_BYTES), rank, n_ranks, C.byref(comm)),
+          "ststhip_comm_create")
+    return comm
+
+
+class Strip:
+    """The native row-strip driver (ststhip_strip_*): one strip of a grid that is cut over several processes / GPUs.
+
+    comm: a communicator from comm_create() joining exactly the strips; or exchange: a Python callable
+    (n_planes, send_up, send_down, recv_up, recv_down, row_bytes, n_rows, stream) -> None with the lists of device
+    pointers of ststhip_comm_exchange_rows, for hosts whose ranks RCCL cannot join (tests)."""
+
+    def __init__(self, app, tf_params, halo_bytes, total_rows, width, rank, n_ranks, comm=None, exchange=None):
+        self._callback = None
+        cb = None
+        if exchange is not None:
+            def trampoline(_ctx, n_planes, su, sd, ru, rd, rb, n_rows, stream):
+                try:
+                    exchange(n_planes, [su[i] for i in range(n_planes)], [sd[i] for i in range(n_planes)],
+                             [ru[i] for i in range(n_planes)], [rd[i] for i in range(n_planes)],
+                             [rb[i] for i in range(n_planes)], int(n_rows), stream)
+                    return 0
+                except Exception as e:  # noqa: BLE001 -- reported through the C ABI's status
+                    load().ststhip_set_last_error(str(e).encode())
+                    return 5
+            self._callback = cb = EXCHANGE_FN(trampoline)
+        halo = C.create_string_buffer(bytes(halo_bytes), len(halo_bytes))
+        self.handle = C.c_void_p()
+        self.tf_params = tf_params
+        check(load().ststhip_strip_create(app.encode(), C.cast(C.byref(tf_params), C.c_void_p), C.cast(halo, C.c_void_p),
+                                          int(total_rows), int(width), int(rank), int(n_ranks), comm,
+                                          C.cast(cb, C.c_void_p) if cb is not None else None, None,
+                                          C.byref(self.handle)), f"ststhip_strip_create({app})")
+        a, b = C.c_uint64(), C.c_uint64()
+        check(load().ststhip_strip_rows(self.handle, C.byref(a), C.byref(b)), "ststhip_strip_rows")
+        self.row_begin, self.row_end = int(a.value), int(b.value)
+        s = C.c_void_p()
+        check(load().ststhip_strip_stream(self.handle, C.byref(s)), "ststhip_strip_stream")
+        self.stream = s.value
+
+    def plane(self, index=0):
+        """(device pointer of the first owned row of the current buffers, bytes per row)"""
+        ptr, row_bytes = C.c_void_p(), C.c_size_t()
+        check(load().ststhip_strip_plane(self.handle, index, C.byref(ptr), C.byref(row_bytes)), "ststhip_strip_plane")
+        return ptr.value, int(row_bytes.value)
+
+    def upload(self, index, host_array):
+        import numpy as np
+
+        rows = np.ascontiguousarray(host_array)
+        ptr, row_bytes = self.plane(index)
+        assert rows.nbytes == row_bytes * (self.row_end - self.row_begin), "array does not match the strip's plane"
+        check(load().ststhip_memcpy_h2d(C.c_void_p(ptr), rows.ctypes.data_as(C.c_void_p), rows.nbytes,
+                                        C.c_void_p(self.stream)), "ststhip_memcpy_h2d")
+        self.synchronize()
+
+    def upload_from_device(self, index, device_ptr, nbytes):
+        ptr, row_bytes = self.plane(index)
+        assert nbytes == row_bytes * (self.row_end - self.row_begin), "buffer does not match the strip's plane"
+        check(load().ststhip_memcpy_d2d(C.c_void_p(ptr), C.c_void_p(int(device_ptr)), nbytes, C.c_void_p(self.stream)),
+              "ststhip_memcpy_d2d")
+
+    def download(self, index, dtype):
+        import numpy as np
+
+        ptr, row_bytes = self.plane(index)
+        out = np.empty((self.row_end - self.row_begin, row_bytes // np.dtype(dtype).itemsize), dtype=dtype)
+        self.synchronize()
+        check(load().ststhip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes,
+                                        C.c_void_p(self.stream)), "ststhip_memcpy_d2h")
+        self.synchronize()
+        return out
+
+    def warm_up(self):
+        check(load().ststhip_strip_warm_up(self.handle), "ststhip_strip_warm_up")
+
+    def advance(self, iteration_offset, n_generations, blocking=False):
+        check(load().ststhip_strip_advance(self.handle, int(iteration_offset), int(n_generations), int(bool(blocking))),
+              "ststhip_strip_advance")
+
+    def synchronize(self):
+        check(load().ststhip_strip_synchronize(self.handle), "ststhip_strip_synchronize")
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(load().ststhip_strip_counters(self.handle, C.byref(a), C.byref(b)), "ststhip_strip_counters")
+        return int(a.value), int(b.value)
+
+    def close(self):
+        if self.handle:
+            load().ststhip_strip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def scatter_fields(aos_ptr, cell_size, n_cells, offsets, sizes, plane_ptrs, stream=0):

@@ -76,12 +76,10 @@ template <typename F, bool SOA> struct AppAdapter {
         e.info.max_generations = Tuning::max_generations;
         e.info.tdv_size = std::is_same_v<TDV, std::monostate> ? 0 : std::uint32_t(sizeof(TDV));
         e.info.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
-        e.info.strip_width = std::uint32_t(
-            stencil::hip::internal::Sweep<F, SOA, Tuning::max_generations, Tuning::cells_per_lane,
-                                          Tuning::prefetch_rows, Tuning::interior_variant>::OW);
+        e.info.strip_width = std::uint32_t(stencil::hip::internal::SweepOf<F, SOA>::OW_PER_WAVE);
         e.info.cells_per_lane = std::uint32_t(Tuning::cells_per_lane);
         e.info.prefetch_rows = std::uint32_t(Tuning::prefetch_rows);
-        e.info.cooperative = 0;
+        e.info.cooperative = stencil::hip::internal::cooperative_for<F, SOA>() ? 1u : 0u;
         e.sweep = &sweep;
         return e;
     }
@@ -89,7 +87,7 @@ template <typename F, bool SOA> struct AppAdapter {
 
 // A transition function with an explicit pipeline shape (used to register tuning experiments and
 // hand-picked shapes next to the heuristic default).
-template <typename F, int K, int T, int P, int MINW = 1, bool INTERIOR = true> struct Shaped : public F {
+template <typename F, int K, int T, int P, int MINW = 1, bool INTERIOR = true, bool COOP = false, int DBG = 0> struct Shaped : public F {
     using Block = typename F::Block;
     Shaped() = default;
     Shaped(F const &f) : F(f) {}
@@ -104,13 +102,18 @@ struct AppRegistrar {
 
 namespace stencil {
 namespace hip {
-template <typename F, int K, int T, int P, int MINW, bool INTERIOR, bool SOA>
-struct SweepTuning<::ststhip_detail::Shaped<F, K, T, P, MINW, INTERIOR>, SOA> {
+template <typename F, int K, int T, int P, int MINW, bool INTERIOR, bool COOP, int DBG, bool SOA>
+struct SweepTuning<::ststhip_detail::Shaped<F, K, T, P, MINW, INTERIOR, COOP, DBG>, SOA> {
+    static constexpr int cooperative_debug = DBG;
     static constexpr int cells_per_lane = K;
     static constexpr int max_generations = T;
     static constexpr int prefetch_rows = P;
     static constexpr bool interior_variant = INTERIOR;
     static constexpr int min_waves_per_simd = MINW;
+    static constexpr bool cooperative = COOP;
+    // hints the wrapped function's own tuning carries
+    static constexpr bool trapezoid_fill = internal::trapezoid_fill_for<F, SOA>();
+    static constexpr bool streaming_stores = internal::streaming_stores_for<F, SOA>();
 };
 } // namespace hip
 } // namespace stencil

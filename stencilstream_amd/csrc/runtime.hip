@@ -213,6 +213,50 @@ __global__ void __launch_bounds__(transform_tile)
     }
 }
 
+// ------------------------------------------------------------------ max |field| reduction
+struct ReduceTable {
+    int n_fields;
+    unsigned offset[8];
+    unsigned type[8];
+    unsigned long long row_limit[8], col_limit[8];
+};
+
+// A wave reduces its 64 cells per field with DPP-based shuffles and adds one atomic max; |x| >= 0, so the bit
+// patterns of the doubles order like the values and an unsigned 64-bit max is exact.
+__global__ void __launch_bounds__(256)
+    reduce_max_abs_kernel(const unsigned char *cells, unsigned cell_size, unsigned long long height,
+                          unsigned long long width, unsigned long long pitch, ReduceTable table,
+                          unsigned long long *acc) {
+    double best[8];
+    for (int f = 0; f < 8; f++)
+        best[f] = 0.0;
+    const unsigned long long n = height * width;
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < n; i += 256ull * gridDim.x) {
+        const unsigned long long r = i / width, c = i - r * width;
+        const unsigned char *cell = cells + (r * pitch + c) * cell_size;
+        for (int f = 0; f < table.n_fields; f++) {
+            if (r < table.row_limit[f] && c < table.col_limit[f]) {
+                double v;
+                if (table.type[f] == STSTHIP_F64)
+                    v = fabs(*reinterpret_cast<const double *>(cell + table.offset[f]));
+                else
+                    v = double(fabsf(*reinterpret_cast<const float *>(cell + table.offset[f])));
+                if (v > best[f]) // false for NaN
+                    best[f] = v;
+            }
+        }
+    }
+    for (int f = 0; f < table.n_fields; f++) {
+        double v = best[f];
+        for (int delta = 32; delta >= 1; delta >>= 1) {
+            const double other = __shfl_xor(v, delta, 64);
+            v = other > v ? other : v;
+        }
+        if ((threadIdx.x & 63) == 0 && v > 0.0)
+            atomicMax(acc + f, static_cast<unsigned long long>(__double_as_longlong(v)));
+    }
+}
+
 static int fill_table(FieldTable &t, std::size_t cell_size, int n_fields, const size_t *offset,
                       const size_t *size, void *const *planes) {
     if (n_fields < 1 || n_fields > 16 || cell_size == 0 || cell_size > 256)
@@ -725,6 +769,63 @@ int ststhip_gather_fields(void *aos, size_t cell_size, size_t n_cells, int n_fie
     return STSTHIP_OK;
 }
 
+int ststhip_reduce_max_abs(const void *cells, size_t cell_size, uint64_t height, uint64_t width,
+                           uint64_t pitch, int n_fields, const ststhip_reduce_field *fields,
+                           double *result, ststhip_stream stream) {
+    if (!fields || !result || n_fields < 1 || n_fields > 8 || cell_size == 0 || pitch < width)
+        return fail(STSTHIP_ERR_INVALID, "reduce_max_abs: need 1..8 fields, a result buffer and pitch >= width");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    ReduceTable table;
+    table.n_fields = n_fields;
+    bool any = false;
+    for (int f = 0; f < n_fields; f++) {
+        const size_t size = fields[f].type == STSTHIP_F64 ? 8 : 4;
+        if (fields[f].type > STSTHIP_F64 || fields[f].offset + size > cell_size || fields[f].offset % size != 0 ||
+            cell_size % size != 0)
+            return fail(STSTHIP_ERR_INVALID, "reduce_max_abs: field outside the cell, misaligned or of unknown type");
+        table.offset[f] = fields[f].offset;
+        table.type[f] = fields[f].type;
+        table.row_limit[f] = fields[f].row_limit < height ? fields[f].row_limit : height;
+        table.col_limit[f] = fields[f].col_limit < width ? fields[f].col_limit : width;
+        any = any || (table.row_limit[f] > 0 && table.col_limit[f] > 0);
+        result[f] = -HUGE_VAL;
+    }
+    if (!any)
+        return STSTHIP_OK;
+    if (!cells)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    hipStream_t s = resolve(stream);
+    void *acc = nullptr;
+    if (int rc = ststhip_malloc_async(&acc, 8 * sizeof(unsigned long long), stream))
+        return rc;
+    unsigned long long host[8] = {0};
+    int rc = STSTHIP_OK;
+    hipError_t err = hipMemsetAsync(acc, 0, sizeof host, s);
+    if (err == hipSuccess) {
+        const unsigned long long n = height * width;
+        const unsigned blocks = unsigned(std::min<unsigned long long>((n + 255) / 256, 16ull * rt().compute_units));
+        hipLaunchKernelGGL(reduce_max_abs_kernel, dim3(blocks), dim3(256), 0, s,
+                           static_cast<const unsigned char *>(cells), unsigned(cell_size),
+                           (unsigned long long)height, (unsigned long long)width, (unsigned long long)pitch, table,
+                           static_cast<unsigned long long *>(acc));
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(host, acc, sizeof host, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess)
+        err = hipStreamSynchronize(s);
+    if (err != hipSuccess)
+        rc = hip_fail(err, "reduce_max_abs");
+    ststhip_free_async(acc, stream);
+    if (rc != STSTHIP_OK)
+        return rc;
+    for (int f = 0; f < n_fields; f++)
+        if (table.row_limit[f] > 0 && table.col_limit[f] > 0)
+            std::memcpy(&result[f], &host[f], sizeof(double)); // >= +0: at least one cell counted
+    return STSTHIP_OK;
+}
+
 // ------------------------------------------------------------------ layer 1
 int ststhip_app_count(void) { return int(apps().size()); }
 
@@ -1022,6 +1123,89 @@ int ststhip_suggest_row_strips(const char *app, uint64_t rows, uint64_t width, u
                               n_passes);
 }
 
+// What ststhip_app_run and the strip driver launch for (app, parameters, halo, geometry): the registered sweep, or
+// one of the two bit-identical fast forms the library switches to on its own (ststhip.h, ststhip_app_run).
+namespace {
+struct ResolvedApp {
+    const AppEntry *entry = nullptr; // geometry and planes (the middle-launch kernel for the uniform form)
+    ststhip_sweep_fn trampoline = nullptr;
+    void *ctx = nullptr;
+    bool uniform = false, packed = false;
+    UniformJacobiCall uniform_call;
+    AppCall call;
+    std::uint32_t dead_word = 0;
+    ststhip_domain words; // packed Game of Life: the domain in 32-bit words
+    ststhip_sweep_desc desc;
+    // the form is chosen for a run of generations [first, last]; a later run may move the window
+    void set_run(std::uint64_t iteration_offset, std::uint64_t n_iterations) {
+        uniform_call.first_iteration = iteration_offset;
+        uniform_call.last_iteration = iteration_offset + n_iterations - 1;
+    }
+};
+
+// `r` must stay where it is afterwards (its context pointers point into it).  `dom` may be replaced by r.words.
+int resolve_app(ResolvedApp &r, const char *app, const void *tf_params, const void *halo_cell,
+                const ststhip_domain *&dom, const void *const *src, void *const *dst, bool have_planes) {
+    const AppEntry *e = find_app(app);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    // Jacobi5General with five equal positive coefficients and a +0 halo: bit-identical results from the
+    // product-carrying form with 5 instead of 9 flops per cell (apps/jacobi.hpp, Jacobi5Uniform)
+    if (std::strcmp(app, "jacobi5general") == 0 && stencil::hip::internal::env_int("STSTHIP_JACOBI_FASTPATH", 1)) {
+        const ststhip_jacobi_params *jp = static_cast<const ststhip_jacobi_params *>(tf_params);
+        std::uint32_t halo_bits;
+        std::memcpy(&halo_bits, halo_cell, sizeof halo_bits);
+        bool same = jp->coef[0] > 0.0f && halo_bits == 0u;
+        for (int i = 1; i < 5 && same; i++)
+            same = std::memcmp(&jp->coef[i], &jp->coef[0], sizeof(float)) == 0;
+        UniformJacobiCall &u = r.uniform_call;
+        u.middle = find_app("jacobi5uniform");
+        u.first = find_app("jacobi5uniform_first");
+        u.last = find_app("jacobi5uniform_last");
+        u.only = find_app("jacobi5uniform_only");
+        if (same && u.middle && u.first && u.last && u.only) {
+            u.c = jp->coef[0];
+            u.halo_cell = halo_cell;
+            r.uniform = true;
+            e = u.middle; // same geometry for all four variants
+        }
+    }
+    // Game of Life with a dead halo on a grid whose width and pitch are multiples of four cells: the same
+    // rule on 32-bit words of four cells (apps/conway.hpp, ConwayPacked), swept as a grid of words
+    if (std::strcmp(app, "conway") == 0 && dom->global_width > 0 && dom->global_width % 4 == 0 &&
+        dom->pitch % 4 == 0 && *static_cast<const unsigned char *>(halo_cell) == 0 &&
+        (!have_planes || (reinterpret_cast<std::uintptr_t>(src[0]) % 4 == 0 &&
+                          reinterpret_cast<std::uintptr_t>(dst[0]) % 4 == 0)) &&
+        stencil::hip::internal::env_int("STSTHIP_CONWAY_FASTPATH", 1)) {
+        if (const AppEntry *packed = find_app("conway_packed")) {
+            e = packed;
+            r.words = *dom;
+            r.words.global_width = dom->global_width / 4;
+            r.words.pitch = dom->pitch / 4;
+            dom = &r.words;
+            r.packed = true;
+        }
+    }
+    r.entry = e;
+    std::memset(&r.desc, 0, sizeof r.desc);
+    r.desc.n_planes = e->info.n_planes;
+    r.desc.max_generations = e->info.max_generations;
+    r.desc.halo_depth_per_generation = e->info.halo_depth_per_generation;
+    r.desc.strip_width = e->info.strip_width;
+    for (unsigned p = 0; p < e->info.n_planes; p++)
+        r.desc.plane_elem_size[p] = e->info.plane_elem_size[p];
+    if (r.uniform) {
+        r.trampoline = uniform_jacobi_trampoline;
+        r.ctx = &r.uniform_call;
+    } else {
+        r.call = AppCall{e, tf_params, r.packed ? static_cast<const void *>(&r.dead_word) : halo_cell};
+        r.trampoline = app_sweep_trampoline;
+        r.ctx = &r.call;
+    }
+    return STSTHIP_OK;
+}
+} // namespace
+
 int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cell,
                     const ststhip_domain *dom, const void *const *src, void *const *dst,
                     uint64_t iteration_offset, uint64_t n_iterations, int blocking, int profiling,
@@ -1036,64 +1220,26 @@ int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cel
     for (unsigned p = 0; p < e->info.n_planes; p++)
         if (!src[p] || !dst[p] || src[p] == dst[p])
             return fail(STSTHIP_ERR_INVALID, "source and target planes must be distinct non-null buffers");
-    // Jacobi5General with five equal positive coefficients and a +0 halo: bit-identical results from the
-    // product-carrying form with 5 instead of 9 flops per cell (apps/jacobi.hpp, Jacobi5Uniform)
-    UniformJacobiCall uniform;
-    bool use_uniform = false;
-    if (std::strcmp(app, "jacobi5general") == 0 && n_iterations > 0 &&
-        stencil::hip::internal::env_int("STSTHIP_JACOBI_FASTPATH", 1)) {
-        const ststhip_jacobi_params *jp = static_cast<const ststhip_jacobi_params *>(tf_params);
-        std::uint32_t halo_bits;
-        std::memcpy(&halo_bits, halo_cell, sizeof halo_bits);
-        bool same = jp->coef[0] > 0.0f && halo_bits == 0u;
-        for (int i = 1; i < 5 && same; i++)
-            same = std::memcmp(&jp->coef[i], &jp->coef[0], sizeof(float)) == 0;
-        uniform.middle = find_app("jacobi5uniform");
-        uniform.first = find_app("jacobi5uniform_first");
-        uniform.last = find_app("jacobi5uniform_last");
-        uniform.only = find_app("jacobi5uniform_only");
-        if (same && uniform.middle && uniform.first && uniform.last && uniform.only) {
-            uniform.c = jp->coef[0];
-            uniform.halo_cell = halo_cell;
-            uniform.first_iteration = iteration_offset;
-            uniform.last_iteration = iteration_offset + n_iterations - 1;
-            use_uniform = true;
-            e = uniform.middle; // same geometry for all four variants
-        }
+    ResolvedApp r;
+    if (n_iterations == 0) { // a copy: no form to choose
+        ststhip_sweep_desc desc;
+        std::memset(&desc, 0, sizeof desc);
+        desc.n_planes = e->info.n_planes;
+        desc.max_generations = e->info.max_generations;
+        desc.halo_depth_per_generation = e->info.halo_depth_per_generation;
+        desc.strip_width = e->info.strip_width;
+        for (unsigned p = 0; p < e->info.n_planes; p++)
+            desc.plane_elem_size[p] = e->info.plane_elem_size[p];
+        AppCall call{e, tf_params, halo_cell};
+        return ststhip_run_passes(app_sweep_trampoline, &call, &desc, dom, src, dst, iteration_offset, 0, blocking,
+                                  profiling, stream, info);
     }
-    // Game of Life with a dead halo on a grid whose width and pitch are multiples of four cells: the same
-    // rule on 32-bit words of four cells (apps/conway.hpp, ConwayPacked), swept as a grid of words
-    ststhip_domain words;
-    bool use_packed = false;
-    if (std::strcmp(app, "conway") == 0 && n_iterations > 0 && dom->global_width > 0 &&
-        dom->global_width % 4 == 0 && dom->pitch % 4 == 0 && *static_cast<const unsigned char *>(halo_cell) == 0 &&
-        reinterpret_cast<std::uintptr_t>(src[0]) % 4 == 0 && reinterpret_cast<std::uintptr_t>(dst[0]) % 4 == 0 &&
-        stencil::hip::internal::env_int("STSTHIP_CONWAY_FASTPATH", 1)) {
-        if (const AppEntry *packed = find_app("conway_packed")) {
-            e = packed;
-            words = *dom;
-            words.global_width = dom->global_width / 4;
-            words.pitch = dom->pitch / 4;
-            dom = &words;
-            use_packed = true;
-        }
-    }
-    ststhip_sweep_desc desc;
-    std::memset(&desc, 0, sizeof desc);
-    desc.n_planes = e->info.n_planes;
-    desc.max_generations = e->info.max_generations;
-    desc.halo_depth_per_generation = e->info.halo_depth_per_generation;
-    desc.strip_width = e->info.strip_width;
-    for (unsigned p = 0; p < e->info.n_planes; p++)
-        desc.plane_elem_size[p] = e->info.plane_elem_size[p];
-    if (use_uniform)
-        return ststhip_run_passes(uniform_jacobi_trampoline, &uniform, &desc, dom, src, dst, iteration_offset,
-                                  n_iterations, blocking, profiling, stream, info);
-    const std::uint32_t dead_word = 0;
-    AppCall call{e, tf_params, use_packed ? static_cast<const void *>(&dead_word) : halo_cell};
-    const int rc = ststhip_run_passes(app_sweep_trampoline, &call, &desc, dom, src, dst, iteration_offset,
-                                      n_iterations, blocking, profiling, stream, info);
-    if (use_packed && info)
+    if (int rc = resolve_app(r, app, tf_params, halo_cell, dom, src, dst, true))
+        return rc;
+    r.set_run(iteration_offset, n_iterations);
+    const int rc = ststhip_run_passes(r.trampoline, r.ctx, &r.desc, dom, src, dst, iteration_offset, n_iterations,
+                                      blocking, profiling, stream, info);
+    if (r.packed && info)
         info->n_processed_cells *= 4; // counted in words by the pass driver
     return rc;
 }
@@ -1166,6 +1312,350 @@ int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *cons
     }
     NCCL_TRY(rccl().GroupEnd());
     return STSTHIP_OK;
+}
+
+
+// ------------------------------------------------------------------ row-strip driver (one strip per process / GPU)
+namespace {
+struct Strip {
+    std::string app;
+    std::vector<unsigned char> params, halo;
+    ResolvedApp resolved;
+    int rank = 0, n_ranks = 1;
+    Comm *comm = nullptr;
+    ststhip_exchange_fn exchange = nullptr;
+    void *exchange_ctx = nullptr;
+    std::uint64_t total_rows = 0, width = 0, row_begin = 0, row_end = 0, g_max = 0, local_rows = 0;
+    std::int64_t row_origin = 0;
+    unsigned n_planes = 0;
+    std::size_t elem[16] = {0};
+    void *planes[2][16] = {{nullptr}};
+    int current = 0;
+    hipStream_t compute = nullptr, comm_stream = nullptr;
+    std::vector<hipStream_t> side;
+    ststhip_domain dom;        // geometry of the buffers (in words for the packed Game of Life)
+    std::uint64_t n_launches = 0, n_exchanges = 0;
+};
+
+void strip_bounds(std::uint64_t total, int n, int r, std::uint64_t &a, std::uint64_t &b) {
+    // as even as possible, earlier ranks take the remainder (stencilstream_amd/dist.py: split_rows)
+    const std::uint64_t base = total / n, extra = total % n;
+    a = base * r + std::min<std::uint64_t>(r, extra);
+    b = a + base + (std::uint64_t(r) < extra ? 1 : 0);
+}
+
+// ghost rows of depth g next to the owned rows of buffer set `set`, on the comm stream
+int strip_exchange(Strip &st, int set, std::uint64_t g) {
+    if (st.n_ranks == 1 || g == 0)
+        return STSTHIP_OK;
+    const void *send_up[16], *send_down[16];
+    void *recv_up[16], *recv_down[16];
+    std::size_t row_bytes[16];
+    const std::uint64_t o_start = st.g_max, o_stop = st.g_max + (st.row_end - st.row_begin);
+    for (unsigned p = 0; p < st.n_planes; p++) {
+        row_bytes[p] = std::size_t(st.dom.pitch) * st.elem[p];
+        unsigned char *base = static_cast<unsigned char *>(st.planes[set][p]);
+        send_up[p] = base + o_start * row_bytes[p];
+        recv_up[p] = base + (o_start - g) * row_bytes[p];
+        send_down[p] = base + (o_stop - g) * row_bytes[p];
+        recv_down[p] = base + o_stop * row_bytes[p];
+    }
+    st.n_exchanges++;
+    if (st.comm)
+        return ststhip_comm_exchange_rows(st.comm, int(st.n_planes), send_up, send_down, recv_up, recv_down, row_bytes,
+                                          std::size_t(g), st.comm_stream);
+    return st.exchange(st.exchange_ctx, int(st.n_planes), send_up, send_down, recv_up, recv_down, row_bytes,
+                       std::size_t(g), st.comm_stream);
+}
+} // namespace
+
+int ststhip_strip_create(const char *app, const void *tf_params, const void *halo_cell, uint64_t total_rows,
+                         uint64_t width, int rank, int n_ranks, ststhip_comm comm, ststhip_exchange_fn exchange,
+                         void *exchange_ctx, ststhip_strip *strip) {
+    const AppEntry *e = find_app(app);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    if (!tf_params || !halo_cell || !strip || n_ranks < 1 || rank < 0 || rank >= n_ranks || width == 0)
+        return fail(STSTHIP_ERR_INVALID, "bad strip arguments");
+    if (n_ranks > 1 && !comm && !exchange)
+        return fail(STSTHIP_ERR_INVALID, "several strips need a communicator or an exchange callback");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    Strip *st = new Strip;
+    st->app = app;
+    st->params.assign(static_cast<const unsigned char *>(tf_params),
+                      static_cast<const unsigned char *>(tf_params) + std::max<std::uint32_t>(e->info.params_size, 1));
+    st->halo.assign(static_cast<const unsigned char *>(halo_cell),
+                    static_cast<const unsigned char *>(halo_cell) + e->info.cell_size);
+    st->rank = rank;
+    st->n_ranks = n_ranks;
+    st->comm = static_cast<Comm *>(comm);
+    st->exchange = exchange;
+    st->exchange_ctx = exchange_ctx;
+    st->total_rows = total_rows;
+    st->width = width;
+    strip_bounds(total_rows, n_ranks, rank, st->row_begin, st->row_end);
+    ststhip_domain whole;
+    whole.global_height = total_rows;
+    whole.global_width = width;
+    whole.pitch = width;
+    whole.row_origin = 0;
+    whole.local_rows = total_rows;
+    const ststhip_domain *dom = &whole;
+    int rc = resolve_app(st->resolved, st->app.c_str(), st->params.data(), st->halo.data(), dom, nullptr, nullptr, false);
+    if (rc != STSTHIP_OK) {
+        delete st;
+        return rc;
+    }
+    e = st->resolved.entry;
+    st->n_planes = e->info.n_planes;
+    st->g_max = std::uint64_t(e->info.max_generations) * e->info.halo_depth_per_generation;
+    std::uint64_t thinnest = total_rows;
+    for (int r = 0; r < n_ranks; r++) {
+        std::uint64_t a, b;
+        strip_bounds(total_rows, n_ranks, r, a, b);
+        thinnest = std::min(thinnest, b - a);
+    }
+    if (n_ranks > 1 && thinnest < 2 * st->g_max) {
+        delete st;
+        return fail(STSTHIP_ERR_INVALID, "strips are thinner than two halo depths: use fewer ranks or a larger grid");
+    }
+    st->row_origin = std::int64_t(st->row_begin) - std::int64_t(st->g_max);
+    st->local_rows = (st->row_end - st->row_begin) + 2 * st->g_max;
+    st->dom = *dom; // width and pitch possibly in words
+    st->dom.row_origin = st->row_origin;
+    st->dom.local_rows = st->local_rows;
+    hipError_t err = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
+    if (err == hipSuccess)
+        err = hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking);
+    for (int set = 0; set < 2 && err == hipSuccess && rc == STSTHIP_OK; set++)
+        for (unsigned p = 0; p < st->n_planes && rc == STSTHIP_OK; p++) {
+            st->elem[p] = e->info.plane_elem_size[p];
+            const std::size_t bytes = std::size_t(st->local_rows) * st->dom.pitch * st->elem[p];
+            rc = ststhip_malloc_async(&st->planes[set][p], bytes, st->compute);
+            if (rc == STSTHIP_OK)
+                err = hipMemsetAsync(st->planes[set][p], 0, bytes, st->compute);
+        }
+    if (err != hipSuccess)
+        rc = hip_fail(err, "strip set-up");
+    if (rc == STSTHIP_OK && (err = hipStreamSynchronize(st->compute)) != hipSuccess)
+        rc = hip_fail(err, "strip set-up");
+    if (rc != STSTHIP_OK) {
+        ststhip_strip_destroy(st);
+        return rc;
+    }
+    *strip = st;
+    return STSTHIP_OK;
+}
+
+int ststhip_strip_destroy(ststhip_strip strip) {
+    Strip *st = static_cast<Strip *>(strip);
+    if (!st)
+        return STSTHIP_OK;
+    if (st->compute)
+        (void)hipStreamSynchronize(st->compute);
+    if (st->comm_stream)
+        (void)hipStreamSynchronize(st->comm_stream);
+    for (hipStream_t lane : st->side) {
+        (void)hipStreamSynchronize(lane);
+        (void)hipStreamDestroy(lane);
+    }
+    for (auto &set : st->planes)
+        for (void *plane : set)
+            if (plane)
+                ststhip_free(plane);
+    if (st->compute)
+        (void)hipStreamDestroy(st->compute);
+    if (st->comm_stream)
+        (void)hipStreamDestroy(st->comm_stream);
+    delete st;
+    return STSTHIP_OK;
+}
+
+int ststhip_strip_rows(ststhip_strip strip, uint64_t *row_begin, uint64_t *row_end) {
+    Strip *st = static_cast<Strip *>(strip);
+    if (!st || !row_begin || !row_end)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    *row_begin = st->row_begin;
+    *row_end = st->row_end;
+    return STSTHIP_OK;
+}
+
+int ststhip_strip_plane(ststhip_strip strip, unsigned plane, void **owned_rows, size_t *row_bytes) {
+    Strip *st = static_cast<Strip *>(strip);
+    if (!st || plane >= st->n_planes || !owned_rows)
+        return fail(STSTHIP_ERR_INVALID, "bad plane index or null argument");
+    const std::size_t bytes = std::size_t(st->dom.pitch) * st->elem[plane];
+    *owned_rows = static_cast<unsigned char *>(st->planes[st->current][plane]) + st->g_max * bytes;
+    if (row_bytes)
+        *row_bytes = bytes;
+    return STSTHIP_OK;
+}
+
+int ststhip_strip_stream(ststhip_strip strip, ststhip_stream *stream) {
+    Strip *st = static_cast<Strip *>(strip);
+    if (!st || !stream)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    *stream = st->compute;
+    return STSTHIP_OK;
+}
+
+int ststhip_strip_synchronize(ststhip_strip strip) {
+    Strip *st = static_cast<Strip *>(strip);
+    if (!st)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipStreamSynchronize(st->compute));
+    return STSTHIP_OK;
+}
+
+int ststhip_strip_counters(ststhip_strip strip, uint64_t *n_launches, uint64_t *n_exchanges) {
+    Strip *st = static_cast<Strip *>(strip);
+    if (!st)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (n_launches)
+        *n_launches = st->n_launches;
+    if (n_exchanges)
+        *n_exchanges = st->n_exchanges;
+    return STSTHIP_OK;
+}
+
+int ststhip_strip_warm_up(ststhip_strip strip) {
+    Strip *st = static_cast<Strip *>(strip);
+    if (!st)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (st->n_ranks == 1)
+        return STSTHIP_OK;
+    HIP_TRY(hipStreamSynchronize(st->compute));
+    if (int rc = strip_exchange(*st, st->current, st->g_max))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(st->comm_stream));
+    return STSTHIP_OK;
+}
+
+// One call = n_generations generations of the whole distributed grid.  Per pass p (buffer sets ping-pong, g = halo
+// rows of the pass):
+//     sub-strip v (own stream): wait(bands of v-1, v+1 of pass p-1; outermost: the ghost rows of pass p)
+//                               -> top band, bottom band -> [bands event] -> interior
+//     comm stream             : wait(bands events of the outermost sub-strips) -> exchange for pass p+1
+// so the exchange for pass p+1 runs beside the interiors of pass p.  A band reads rows up to 2g into its own
+// sub-strip and g into the neighbour, all of the previous pass; bands and interior of one pass write disjoint rows.
+int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64_t n_generations, int blocking) {
+    Strip *st = static_cast<Strip *>(strip);
+    if (!st)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    const AppEntry *e = st->resolved.entry;
+    const std::vector<std::uint32_t> depths = plan_depths(n_generations, e->info.max_generations);
+    if (depths.empty())
+        return STSTHIP_OK;
+    st->resolved.set_run(iteration_offset, n_generations);
+    const std::uint64_t hpg = e->info.halo_depth_per_generation;
+    const std::uint64_t a = st->row_begin, b = st->row_end;
+    int rc = STSTHIP_OK;
+    std::vector<hipEvent_t> events;
+    auto ordered = [&](hipError_t err, const char *what) {
+        if (err != hipSuccess && rc == STSTHIP_OK)
+            rc = hip_fail(err, what);
+    };
+    auto record = [&](hipStream_t on) {
+        hipEvent_t ev = nullptr;
+        ordered(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreateWithFlags");
+        if (ev) {
+            ordered(hipEventRecord(ev, on), "hipEventRecord");
+            events.push_back(ev);
+        }
+        return ev;
+    };
+    auto wait = [&](hipStream_t who, hipEvent_t ev) {
+        if (ev)
+            ordered(hipStreamWaitEvent(who, ev, 0), "hipStreamWaitEvent");
+    };
+
+    // sub-strips of the owned rows, the rule of the single-GPU pass driver
+    int n_sub = suggest_row_strips(b - a, st->dom.global_width, e->info.strip_width, st->g_max, depths.size());
+    n_sub = std::min(n_sub, 2);
+    while (n_sub > 1 && (b - a) < std::uint64_t(n_sub) * 2 * std::max<std::uint64_t>(st->g_max, 1))
+        n_sub--;
+    std::vector<std::uint64_t> bound(n_sub + 1);
+    for (int v = 0; v <= n_sub; v++)
+        bound[v] = a + (b - a) * std::uint64_t(v) / std::uint64_t(n_sub);
+    if (n_sub == 2) // unequal strips drift out of phase, so one strip's tail meets the other's bulk
+        bound[1] = a + (b - a) * 2 / 5;
+    while (int(st->side.size()) < n_sub - 1) {
+        hipStream_t lane;
+        if (hipStreamCreateWithFlags(&lane, hipStreamNonBlocking) != hipSuccess)
+            return hip_fail(hipErrorUnknown, "hipStreamCreateWithFlags");
+        st->side.push_back(lane);
+    }
+    std::vector<hipStream_t> lanes(n_sub, st->compute);
+    for (int v = 1; v < n_sub; v++)
+        lanes[v] = st->side[v - 1];
+    const bool has_up = st->rank > 0, has_down = st->rank + 1 < st->n_ranks;
+    g_launch_concurrency = n_sub;
+
+    hipEvent_t begin = record(st->compute); // everything queued so far: a previous advance, uploads
+    wait(st->comm_stream, begin);
+    for (int v = 1; v < n_sub; v++)
+        wait(lanes[v], begin);
+    hipEvent_t ghosts_ready = nullptr;
+    if (st->n_ranks > 1 && rc == STSTHIP_OK) {
+        rc = strip_exchange(*st, st->current, depths[0] * hpg);
+        ghosts_ready = record(st->comm_stream);
+    }
+    std::vector<hipEvent_t> bands_done(n_sub, nullptr);
+    std::uint64_t iteration = iteration_offset;
+    for (std::size_t i = 0; i < depths.size() && rc == STSTHIP_OK; i++) {
+        const std::uint32_t depth = depths[i];
+        const std::uint64_t g = depth * hpg;
+        const void *const *src = const_cast<const void *const *>(st->planes[st->current]);
+        void *const *dst = st->planes[st->current ^ 1];
+        std::vector<hipEvent_t> bands_now(n_sub, nullptr);
+        for (int v = 0; v < n_sub && rc == STSTHIP_OK; v++) {
+            const std::uint64_t va = bound[v], vb = bound[v + 1];
+            hipStream_t lane = lanes[v];
+            const bool up = v > 0 || has_up;            // somebody above needs (and feeds) my top rows
+            const bool down = v + 1 < n_sub || has_down;
+            if (v > 0)
+                wait(lane, bands_done[v - 1]);
+            if (v + 1 < n_sub)
+                wait(lane, bands_done[v + 1]);
+            if ((v == 0 && has_up) || (v == n_sub - 1 && has_down))
+                wait(lane, ghosts_ready);
+            const std::uint64_t top_end = up ? std::min(va + g, vb) : va;
+            const std::uint64_t bot_begin = down ? std::max(vb - std::min(g, vb - va), top_end) : vb;
+            auto sweep = [&](std::uint64_t r0, std::uint64_t r1) {
+                if (r0 < r1 && rc == STSTHIP_OK) {
+                    rc = st->resolved.trampoline(st->resolved.ctx, &st->dom, src, dst, r0, r1, iteration, depth, lane);
+                    st->n_launches++;
+                }
+            };
+            sweep(va, top_end);
+            sweep(bot_begin, vb);
+            bands_now[v] = record(lane);
+            sweep(top_end, bot_begin);
+        }
+        if (i + 1 < depths.size() && st->n_ranks > 1 && rc == STSTHIP_OK) {
+            wait(st->comm_stream, bands_now[0]);
+            wait(st->comm_stream, bands_now[n_sub - 1]);
+            rc = strip_exchange(*st, st->current ^ 1, depths[i + 1] * hpg);
+            ghosts_ready = record(st->comm_stream);
+        }
+        bands_done.swap(bands_now);
+        st->current ^= 1;
+        iteration += depth;
+    }
+    g_launch_concurrency = 1;
+    // the compute stream is the one callers synchronise with
+    for (int v = 1; v < n_sub; v++)
+        wait(st->compute, record(lanes[v]));
+    wait(st->compute, record(st->comm_stream));
+    if (rc == STSTHIP_OK && blocking) {
+        hipError_t err = hipStreamSynchronize(st->compute);
+        if (err != hipSuccess)
+            rc = hip_fail(err, "hipStreamSynchronize");
+    }
+    for (hipEvent_t ev : events)
+        (void)hipEventDestroy(ev); // released once they have completed
+    return rc;
 }
 
 } // extern "C"

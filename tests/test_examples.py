@@ -193,3 +193,70 @@ def test_convection_hip_matches_cpu_backend(tmp_path):
         a, b = frames["hip"][f], frames["cpu"][f]
         assert a.shape == b.shape
         assert np.allclose(a, b, rtol=1e-10, atol=1e-12), f
+
+
+CONVECTION_EXPERIMENT_256 = dict(CONVECTION_EXPERIMENT, res=256, iterMax=300, nt=2, nerr=100)
+
+
+@pytest.mark.gpu
+def test_convection_res256_hip_and_device_reduction_match_cpu_backend(tmp_path):
+    """res = 256 (767 x 255 cells of 88 bytes), two time steps of up to three blocks of 100 pseudo-transient
+    iterations: the unchanged example on the MI355X backend and the driver with the device-side convergence
+    check (examples/convection_device_reduce.cpp, stencil::hip::max_abs instead of the host scan of
+    convection.cpp:412-438) against the cpu-backend build: same iteration counts per time step, same
+    residuals to the printed digits, every CSV within rtol 1e-10."""
+    bins = {"cpu": exe("convection_cpu"), "hip": exe("convection_hip"), "reduce": exe("convection_reduce_hip")}
+    cfg = tmp_path / "experiment.json"
+    cfg.write_text(json.dumps(CONVECTION_EXPERIMENT_256))
+    frames, steps = {}, {}
+    for name, binary in bins.items():
+        d = tmp_path / name
+        d.mkdir()
+        env = dict(os.environ, OMP_NUM_THREADS="16")
+        res = subprocess.run([binary, str(cfg), str(d)], check=True, capture_output=True, env=env, timeout=900)
+        lines = [l for l in res.stdout.decode().splitlines() if l.startswith("it = ")]
+        # "it = 1 (iter = 300, time = 1.2e-01), errV=1.234e-02, errP=5.678e-03"
+        steps[name] = [(l.split("(iter = ")[1].split(",")[0], l.split("errV=")[1].split(",")[0],
+                        l.split("errP=")[1].strip()) for l in lines]
+        frames[name] = {f: np.loadtxt(d / f, delimiter=",") for f in sorted(os.listdir(d))}
+    assert len(steps["cpu"]) == 2
+    for name in ("hip", "reduce"):
+        assert [s[0] for s in steps[name]] == [s[0] for s in steps["cpu"]], "iteration counts differ"
+        for got, want in zip(steps[name], steps["cpu"]):
+            assert abs(float(got[1]) - float(want[1])) <= 2e-3 * abs(float(want[1]))
+            assert abs(float(got[2]) - float(want[2])) <= 2e-3 * abs(float(want[2]))
+        assert sorted(frames[name]) == sorted(frames["cpu"]) and frames[name]
+        for f in frames[name]:
+            assert np.allclose(frames[name][f], frames["cpu"][f], rtol=1e-10, atol=1e-12), (name, f)
+    # the two GPU drivers run the same kernels on the same data: identical files
+    for f in frames["hip"]:
+        assert np.array_equal(frames["hip"][f], frames["reduce"][f])
+
+
+@pytest.mark.gpu
+def test_reduce_max_abs_matches_numpy(gpu):
+    """ststhip_reduce_max_abs: per-field index limits, f32 and f64 fields, NaNs skipped, empty ranges."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    rng = np.random.default_rng(9)
+    cell = np.dtype([("a", "<f8"), ("b", "<f4"), ("pad", "<f4"), ("c", "<f8")])
+    H, W = 301, 517
+    cells = np.zeros((H, W), dtype=cell)
+    for name in ("a", "b", "c"):
+        cells[name] = rng.standard_normal((H, W)) * 100
+    cells["a"][H - 1, W - 1] = -1e9   # outside the limits below: must not count
+    cells["c"][5, 7] = np.nan
+    cells["b"][200, 300] = -12345.0
+    dev = torch.from_numpy(cells.view(np.uint8).reshape(-1).copy()).to(gpu)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    fields = [(0, "f8", H - 1, W - 1), (8, "f4", H, W), (16, "f8", H, 10), (0, "f8", 0, W), (16, "f8", H, W)]
+    got = capi.reduce_max_abs(dev.data_ptr(), cell.itemsize, H, W, fields, stream=s.cuda_stream)
+    assert got[0] == np.abs(cells["a"][:H - 1, :W - 1]).max()
+    assert got[1] == float(np.abs(cells["b"]).max()) == 12345.0
+    assert got[2] == np.nanmax(np.abs(cells["c"][:, :10]))
+    assert got[3] == -np.inf
+    assert got[4] == np.nanmax(np.abs(cells["c"]))

@@ -104,6 +104,7 @@ def test_hotspot_full_size_windows(gpu, oracle, real):
     # AoS cells: the same result, cell for cell
     aos = torch.stack([temp, power], dim=-1).contiguous()
     out = torch.empty_like(aos)
+    torch.cuda.synchronize()  # filled on torch's stream, swept on `s`
     capi.app_run(names[1], pc, halo, dom, [aos.data_ptr()], [out.data_ptr()], 0, n, blocking=True, stream=s.cuda_stream)
     assert torch.equal(out[..., 0], out_t) and torch.equal(out[..., 1], out_p), "AoS and planes sweeps differ"
 
@@ -197,6 +198,7 @@ def test_fdtd_max_grid_full_size_windows(gpu, oracle, where):
     # per-field planes (stores of ca..db left out from the third launch on): the same cells
     planes = [cells[..., f].contiguous() for f in range(8)]
     outs = [torch.empty_like(p) for p in planes]
+    torch.cuda.synchronize()  # filled on torch's stream, swept on `s`
     capi.app_run("fdtd_coef", pc, halo, dom, [p.data_ptr() for p in planes], [p.data_ptr() for p in outs], offset, n,
                  blocking=True, stream=s.cuda_stream)
     for f in range(8):

@@ -861,3 +861,33 @@ def test_hotspot_fp64_bit_exact(gpu, oracle, split):
         want = oracle.hotspot_f64(po, cells, n, n_threads=8)
         assert np.array_equal(bits(got), bits(want)), f"n={n}"
     assert np.abs(want["temp"] - cells["temp"]).max() > 0
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 700), (300, 257), (700, 1100), (1500, 2300)], ids=str)
+def test_cooperative_strips_bit_exact(gpu, oracle, shape):
+    """Sweep<..., COOP = true>: the waves of a workgroup exchange their edge columns through LDS.  Jacobi5General
+    (one word, K = 4) and HotSpot on planes (two words, K = 1, `power` stores skipped from the third launch on):
+    grids narrower than one workgroup tile, ragged widths, several workgroup columns and row chunks; the launch
+    depths 8 + 4 + 1 and 8 + 8 + 8 + 2; bit for bit against the oracle."""
+    from stencilstream_amd import capi, update as U
+
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    H, W = shape
+    grid = rng.random(shape, dtype=np.float32)
+    coef = [0.1, 0.2, 0.3, 0.25, 0.15]
+    tf = U.TransitionFunction("jacobi5general_coop", U.jacobi("Jacobi5General", coef).params, np.dtype("<f4"))
+    assert capi.app_info("jacobi5general_coop").cooperative == 1
+    for n in (13, 26):
+        got = run_hip(tf, grid, n, halo=np.float32(0.125))
+        want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=0.125, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"jacobi n={n}"
+
+    cells = np.zeros(shape, dtype=U.HOTSPOT_CELL)
+    cells["temp"] = 320 + 10 * rng.random(shape, dtype=np.float32)
+    cells["power"] = rng.random(shape, dtype=np.float32) * 0.01
+    p = oracle.hotspot_params(*shape)
+    tf = U.TransitionFunction("hotspot_coop", capi.HotspotParams(p.Rx_1, p.Ry_1, p.Rz_1, p.Cap_1), U.HOTSPOT_CELL)
+    for n in (3, 26):
+        got = run_hip(tf, cells, n)
+        want = oracle.hotspot(p, cells, n, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"hotspot n={n}"

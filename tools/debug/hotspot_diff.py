@@ -21,6 +21,7 @@ for n in (8, 16, 24, 27):
     capi.app_run("hotspot", pc, halo, dom, [temp.data_ptr(), power.data_ptr()], [out_t.data_ptr(), out_p.data_ptr()], 0, n, blocking=True, stream=s.cuda_stream)
     aos = torch.stack([temp, power], dim=-1).contiguous()
     out = torch.empty_like(aos)
+    torch.cuda.synchronize()  # filled on torch's stream, swept on `s`
     capi.app_run("hotspot_aos", pc, halo, dom, [aos.data_ptr()], [out.data_ptr()], 0, n, blocking=True, stream=s.cuda_stream)
     dt = (out[..., 0] != out_t); dp = (out[..., 1] != out_p)
     print("n", n, "temp diffs", int(dt.sum()), "power diffs", int(dp.sum()))
