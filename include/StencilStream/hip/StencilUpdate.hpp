@@ -17,6 +17,7 @@
 // advances up to SweepTuning<F>::max_generations generations (hip/internal/Sweep.hpp).
 #pragma once
 #include "../Concepts.hpp"
+#include "../tdv/SinglePassStrategies.hpp"
 #include "Grid.hpp"
 #include "internal/Sweep.hpp"
 
@@ -48,9 +49,26 @@ template <typename F> struct SplitCellPolicy {
     }();
 };
 
-template <concepts::TransitionFunction F, bool split_cell_structure = false> class StencilUpdate {
+namespace internal {
+// PrecomputeOnDeviceStrategy: the values of generations [offset, offset + n) computed by the device
+template <typename F>
+__global__ void fill_tdv_kernel(const F f, std::size_t offset, std::size_t n, typename F::TimeDependentValue *values) {
+    const std::size_t i = blockIdx.x * std::size_t(blockDim.x) + threadIdx.x;
+    if (i < n)
+        values[i] = f.get_time_dependent_value(offset + i);
+}
+} // namespace internal
+
+// TDVStrategy (an extension: the reference's cuda::StencilUpdate has two template parameters and always evaluates
+// on the host): where the time-dependent values come from, see tdv/SinglePassStrategies.hpp.  The default gives
+// the kernels the host's values, bit for bit what the reference's cpu / cuda backends feed theirs.
+template <concepts::TransitionFunction F, bool split_cell_structure = false,
+          typename TDVStrategy = tdv::single_pass::PrecomputeOnHostStrategy>
+class StencilUpdate {
     using Cell = typename F::Cell;
     using TDV = typename F::TimeDependentValue;
+    static constexpr bool has_tdv = !std::is_empty_v<TDV>;
+    static constexpr bool inline_tdv = has_tdv && TDVStrategy::kind == tdv::single_pass::Kind::Inline;
     static constexpr bool on_planes = [] {
         if constexpr (split_cell_structure)
             return SplitCellPolicy<F>::sweep_on_planes;
@@ -109,18 +127,24 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
                                 std::uint64_t iteration, std::uint32_t depth, ststhip_stream stream) {
         StencilUpdate const *self = static_cast<StencilUpdate const *>(ctx);
         try {
+            // the launch's values come from the call's device table (ststhip_current_tdv_table) or from the kernel
+            // itself; evaluated here only if there is neither (a driver without a table)
             std::vector<TDV> tdv;
-            tdv.reserve(depth);
-            for (std::uint32_t t = 0; t < depth; t++)
-                tdv.push_back(self->params.transition_function.get_time_dependent_value(iteration + t));
+            const void *table = nullptr;
+            ststhip_current_tdv_table(&table, nullptr, nullptr, nullptr);
+            if (has_tdv && !inline_tdv && !table) {
+                tdv.reserve(depth);
+                for (std::uint32_t t = 0; t < depth; t++)
+                    tdv.push_back(self->params.transition_function.get_time_dependent_value(iteration + t));
+            }
             Planes from, to;
             for (int f = 0; f < Planes::n_planes; f++) {
                 from.plane[f] = const_cast<void *>(src[f]);
                 to.plane[f] = dst[f];
             }
-            internal::dispatch_sweep<F, on_planes>(
-                int(depth), self->params.transition_function, self->params.halo_value, tdv.data(),
-                *dom, from, to, out_begin, out_end, iteration, stream);
+            internal::dispatch_sweep<F, on_planes, SweepTuning<F, on_planes>::max_generations, inline_tdv>(
+                int(depth), self->params.transition_function, self->params.halo_value,
+                tdv.empty() ? nullptr : tdv.data(), *dom, from, to, out_begin, out_end, iteration, stream);
             return STSTHIP_OK;
         } catch (internal::runtime_error const &e) {
             return e.status;
@@ -140,6 +164,30 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
         desc.strip_width = std::uint32_t(internal::SweepOf<F, on_planes>::OW_PER_WAVE);
         for (int f = 0; f < Planes::n_planes; f++)
             desc.plane_elem_size[f] = Planes::elem_size(f);
+        // one device table of time-dependent values per call: filled by the host, or by the device
+        void *device_values = nullptr;
+        if constexpr (has_tdv && !inline_tdv) {
+            desc.tdv_size = sizeof(TDV);
+            if constexpr (TDVStrategy::kind == tdv::single_pass::Kind::PrecomputeOnDevice) {
+                if (params.n_iterations > 0) {
+                    device_values = internal::device_alloc_on(params.n_iterations * sizeof(TDV), stream);
+                    const F f = params.transition_function;
+                    std::size_t offset = params.iteration_offset, n = params.n_iterations;
+                    TDV *out = static_cast<TDV *>(device_values);
+                    void *kernel_args[] = {const_cast<F *>(&f), &offset, &n, &out};
+                    internal::check(ststhip_launch(reinterpret_cast<const void *>(&internal::fill_tdv_kernel<F>),
+                                                   unsigned((n + 255) / 256), 1, 1, 256, 1, 1, kernel_args, 0, stream),
+                                    "time-dependent values");
+                    desc.tdv_device_table = device_values;
+                }
+            } else {
+                desc.fill_tdv = [](void *ctx, std::uint64_t offset, std::uint64_t n, void *values) {
+                    StencilUpdate const *self = static_cast<StencilUpdate const *>(ctx);
+                    for (std::uint64_t i = 0; i < n; i++)
+                        static_cast<TDV *>(values)[i] = self->params.transition_function.get_time_dependent_value(offset + i);
+                };
+            }
+        }
         ststhip_run_info info = {};
         internal::check(ststhip_run_passes(&sweep_trampoline, this, &desc, &dom,
                                            const_cast<const void *const *>(source.plane), target.plane,
@@ -147,6 +195,8 @@ template <concepts::TransitionFunction F, bool split_cell_structure = false> cla
                                            params.profiling ? 1 : 0, stream, &info),
                         "ststhip_run_passes");
         kernel_runtime += info.kernel_time_s;
+        if (device_values)
+            ststhip_free_async(device_values, stream);
     }
 
     GridImpl simulate(GridImpl &source_grid, ststhip_stream stream)

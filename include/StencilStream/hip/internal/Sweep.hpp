@@ -298,9 +298,13 @@ template <typename F, bool SOA> struct SweepTuning {
         return t == 6 && NS >= 2 && k * W <= 8 && nominal_window(t, k) > 128 && nominal_window(t, k) * 2 / 3 <= 128 &&
                geometry_ok(t, k);
     }
+    // Radius 2 and more: a level reads (2R+1)^2 cells and keeps 2R rows, so the arithmetic per cell grows with R^2
+    // while a deeper launch saves the same bytes -- the measured optimum is shallow (dense 5 x 5 Jacobi, 16384^2:
+    // T = 8: 540, 4: 650, 2: 760 Gcell/s, profiles/r02_tune_radius.txt): the window is capped at 32 words there.
+    static constexpr int window_limit = R >= 2 ? 32 : 128;
     static constexpr int pick_t(int k) {
         for (int t : {8, 6, 4, 2})
-            if (t == 6 ? relaxed(t, k) : (nominal_window(t, k) <= 128 && geometry_ok(t, k)))
+            if (t == 6 ? relaxed(t, k) : (nominal_window(t, k) <= window_limit && geometry_ok(t, k)))
                 return t;
         return 1;
     }
@@ -321,6 +325,58 @@ template <typename F, bool SOA> struct SweepTuning {
 };
 
 namespace internal {
+// The same transition function swept with the narrowest lanes (one cell per lane for radius 1): four times as many
+// waves for a thin-cell function whose default shape holds four cells per lane.  The launcher switches to it for
+// grids too small to fill the chip with the default shape (narrow_form_cells below): a launch is then the latency
+// of one wave through its warm-up rows, and narrower lanes mean more waves sharing it.  Measured, Jacobi5General
+// (profiles/r02_small_grids.txt): 256^2 26.7 -> 46.7, 512^2 92 -> 158, 1024^2 310 -> 462, 2048^2 854 -> 1025,
+// 4096^2 1830 -> 1865 Gcell-updates/s; the default shape wins from about 4600^2 on.
+template <typename F> struct NarrowForm : public F {
+    NarrowForm(F const &f) : F(f) {}
+};
+} // namespace internal
+
+template <typename F, bool SOA> struct SweepTuning<internal::NarrowForm<F>, SOA> {
+    static constexpr int cells_per_lane = internal::ceil_pow2(int(F::stencil_radius));
+    static constexpr int max_generations = SweepTuning<F, SOA>::max_generations;
+    static constexpr int prefetch_rows = SweepTuning<F, SOA>::prefetch_rows;
+    static constexpr bool interior_variant = SweepTuning<F, SOA>::interior_variant;
+    static constexpr int min_waves_per_simd = SweepTuning<F, SOA>::min_waves_per_simd;
+    static constexpr bool cooperative = false;
+    static constexpr bool trapezoid_fill = [] {
+        if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })
+            return SweepTuning<F, SOA>::trapezoid_fill;
+        else
+            return internal::cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 4;
+    }();
+    static constexpr bool streaming_stores = [] {
+        if constexpr (requires { SweepTuning<F, SOA>::streaming_stores; })
+            return SweepTuning<F, SOA>::streaming_stores;
+        else
+            return sizeof(typename F::Cell) >= 4 &&
+                   internal::cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 2;
+    }();
+};
+
+namespace internal {
+
+template <typename T> struct is_narrow_form : std::false_type {};
+template <typename F> struct is_narrow_form<NarrowForm<F>> : std::true_type {};
+
+// Does F have a narrower shape worth compiling?  Only functions whose default shape holds several cells per lane
+// and that are not swept cooperatively; the wave of the narrow shape must still produce columns at full depth.
+template <typename F, bool SOA> constexpr bool has_narrow_form() {
+    if constexpr (is_narrow_form<F>::value) {
+        return false;
+    } else {
+        constexpr int k = ceil_pow2(int(F::stencil_radius));
+        constexpr int g = int(F::stencil_radius) * int(F::n_subiterations) * SweepTuning<F, SOA>::max_generations;
+        bool coop = false;
+        if constexpr (requires { SweepTuning<F, SOA>::cooperative; })
+            coop = SweepTuning<F, SOA>::cooperative;
+        return !coop && SweepTuning<F, SOA>::cells_per_lane > k && wave_size * k - 2 * round_up(g, k) >= 16 * k;
+    }
+}
 
 // Geometry of one sweep launch, in global grid coordinates.
 struct SweepGeometry {
@@ -405,7 +461,9 @@ template <typename F, bool SOA> constexpr bool streaming_stores_for() {
 constexpr int waves_per_block = 4; // 4 waves per workgroup: 2 or 1 are 1-3 % slower (profiles/r01_tune_taper.txt)
 
 // COOP_DEBUG (timing experiments only, results are wrong): 1 = no barrier, 2 = no LDS traffic, 3 = neither
-template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT, bool COOP = false, int COOP_DEBUG = 0> struct Sweep {
+template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT, bool COOP = false, int COOP_DEBUG = 0,
+          bool INLINE_TDV = false>
+struct Sweep {
     using Cell = typename F::Cell;
     using TDV = typename F::TimeDependentValue;
     using Planes = PlaneSet<Cell, SOA>;
@@ -443,7 +501,12 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT, bool
     struct Args {
         F f;
         Cell halo;
+        // Time-dependent values of the launch's T generations, one of three sources (tdv/SinglePassStrategies.hpp):
+        // `tdv_table` != nullptr: device array, element i = generation i of this launch (the pass driver's per-call
+        // table: precomputed on the host or on the device); else `tdv`: evaluated on the host for this launch
+        // and shipped as kernel arguments; INLINE_TDV: evaluated by the kernel itself, neither is read.
         TDV tdv[T];
+        TDV const *tdv_table;
         Planes src, dst;
         SweepGeometry geo;
     };
@@ -591,7 +654,14 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT, bool
                     const int j = y - level * R;            // global row this level emits now
                     const std::size_t iteration = g.iteration + std::size_t((level - 1) / NS);
                     const std::size_t subiteration = std::size_t((level - 1) % NS);
-                    TDV const &tdv = a.tdv[(level - 1) / NS];
+                    const TDV tdv = [&]() -> TDV {
+                        if constexpr (std::is_empty_v<TDV>)
+                            return TDV{};
+                        else if constexpr (INLINE_TDV)
+                            return a.f.get_time_dependent_value(iteration);
+                        else
+                            return a.tdv_table ? a.tdv_table[(level - 1) / NS] : a.tdv[(level - 1) / NS];
+                    }();
 
                     // rows j-R .. j+R of the previous level, widened by R cells from both neighbour lanes
                     Cell ext[D][K + 2 * R];
@@ -762,9 +832,10 @@ template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT, bool
 };
 
 // The sweep SweepTuning<F, SOA> asks for, at blocking depth T.
-template <typename F, bool SOA, int T = SweepTuning<F, SOA>::max_generations>
+template <typename F, bool SOA, int T = SweepTuning<F, SOA>::max_generations, bool INLINE_TDV = false>
 using SweepOf = Sweep<F, SOA, T, SweepTuning<F, SOA>::cells_per_lane, SweepTuning<F, SOA>::prefetch_rows,
-                      SweepTuning<F, SOA>::interior_variant, cooperative_for<F, SOA>(), cooperative_debug_for<F, SOA>()>;
+                      SweepTuning<F, SOA>::interior_variant, cooperative_for<F, SOA>(), cooperative_debug_for<F, SOA>(),
+                      INLINE_TDV>;
 
 // MIN_WAVES = waves per SIMD the register allocator must leave room for (launch-bounds semantics).
 template <typename SW, int MIN_WAVES = 1, bool SKIP_CONSTANTS = false>
@@ -859,17 +930,28 @@ inline void plan_tiers(SweepGeometry &g, int out_rows) {
     g.tier_first[g.n_tiers] = g.n_chunks;
 }
 
-// One kernel launch = T generations over global rows [out_begin, out_end).
-template <typename F, bool SOA, int T>
+// One kernel launch = T generations over global rows [out_begin, out_end).  `tdv`: the T time-dependent values
+// evaluated on the host, or nullptr when the kernel takes them from the pass driver's device table
+// (ststhip_current_tdv_table) or evaluates them itself (INLINE_TDV).
+template <typename F, bool SOA, int T, bool INLINE_TDV = false>
 void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDependentValue const *tdv,
                   ststhip_domain const &dom, PlaneSet<typename F::Cell, SOA> const &src,
                   PlaneSet<typename F::Cell, SOA> const &dst, std::uint64_t out_begin,
                   std::uint64_t out_end, std::uint64_t iteration, ststhip_stream stream) {
     using Tuning = SweepTuning<F, SOA>;
-    using SW = SweepOf<F, SOA, T>;
+    using SW = SweepOf<F, SOA, T, INLINE_TDV>;
     constexpr bool coop = cooperative_for<F, SOA>();
     if (out_end <= out_begin || dom.global_width == 0)
         return;
+    if constexpr (has_narrow_form<F, SOA>()) {
+        // grids that cannot fill the chip with this shape: the same function on the narrowest lanes
+        static const std::uint64_t narrow_form_cells = std::uint64_t(env_int("STSTHIP_NARROW_FORM_KCELLS", 20000)) * 1000;
+        if (dom.global_height * dom.global_width <= narrow_form_cells) {
+            launch_sweep<NarrowForm<F>, SOA, T, INLINE_TDV>(NarrowForm<F>(f), halo, tdv, dom, src, dst, out_begin, out_end,
+                                                            iteration, stream);
+            return;
+        }
+    }
     if (dom.global_height >= (1ull << 31) || dom.global_width >= (1ull << 31))
         throw std::range_error("grid extents must be below 2^31 per dimension");
 
@@ -907,9 +989,21 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     g.xcd_remap = env_int("STSTHIP_XCD_REMAP", 0) ? 1u : 0u;
     g.last_chunk_early = (out_end + SW::G > dom.global_height && env_int("STSTHIP_LAST_CHUNK_EARLY", 1)) ? 1u : 0u;
 
+    using TDV = typename F::TimeDependentValue;
+    TDV const *table = nullptr;
+    if constexpr (!std::is_empty_v<TDV> && !INLINE_TDV) {
+        const void *base = nullptr;
+        std::uint64_t first_iteration = 0, n_values = 0, value_size = 0;
+        ststhip_current_tdv_table(&base, &first_iteration, &n_values, &value_size);
+        if (base && value_size == sizeof(TDV) && iteration >= first_iteration &&
+            iteration + std::uint64_t(T) <= first_iteration + n_values)
+            table = static_cast<TDV const *>(base) + (iteration - first_iteration);
+        else if (!tdv)
+            throw std::invalid_argument("no time-dependent values for this launch");
+    }
     // transition functions need not be default-constructible: build the argument block in one go
     typename SW::Args args = [&]<std::size_t... Is>(std::index_sequence<Is...>) {
-        return typename SW::Args{f, halo, {tdv[Is]...}, src, dst, g};
+        return typename SW::Args{f, halo, {((table || !tdv) ? TDV{} : tdv[Is])...}, table, src, dst, g};
     }(std::make_index_sequence<std::size_t(T)>{});
 
     const unsigned units = g.n_strips * g.n_chunks;
@@ -921,16 +1015,16 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
 }
 
 // Runtime n_generations -> compiled T (powers of two up to the tuning's maximum).
-template <typename F, bool SOA, int T = SweepTuning<F, SOA>::max_generations>
+template <typename F, bool SOA, int T = SweepTuning<F, SOA>::max_generations, bool INLINE_TDV = false>
 void dispatch_sweep(int n_generations, F const &f, typename F::Cell const &halo,
                     typename F::TimeDependentValue const *tdv, ststhip_domain const &dom,
                     PlaneSet<typename F::Cell, SOA> const &src,
                     PlaneSet<typename F::Cell, SOA> const &dst, std::uint64_t out_begin,
                     std::uint64_t out_end, std::uint64_t iteration, ststhip_stream stream) {
     if (n_generations == T) {
-        launch_sweep<F, SOA, T>(f, halo, tdv, dom, src, dst, out_begin, out_end, iteration, stream);
+        launch_sweep<F, SOA, T, INLINE_TDV>(f, halo, tdv, dom, src, dst, out_begin, out_end, iteration, stream);
     } else if constexpr (T > 1) {
-        dispatch_sweep<F, SOA, T / 2>(n_generations, f, halo, tdv, dom, src, dst, out_begin,
+        dispatch_sweep<F, SOA, T / 2, INLINE_TDV>(n_generations, f, halo, tdv, dom, src, dst, out_begin,
                                       out_end, iteration, stream);
     } else {
         throw std::invalid_argument("n_generations is not a compiled temporal-blocking depth");

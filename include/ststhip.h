@@ -117,6 +117,12 @@ int ststhip_launch_concurrency(void);
  * sweep launcher then leaves out the stores of the per-field planes a transition function declares constant
  * (F::constant_fields): they already hold those values. */
 int ststhip_target_holds_constants(void);
+/* The device table of time-dependent values the pass driver has built for the call it is in (ststhip_sweep_desc:
+ * tdv_size / fill_tdv / tdv_device_table), for the calling thread: `base` = value of generation `first_iteration`,
+ * `n_values` of `value_size` bytes; base = NULL outside of such a call.  The sweep launcher points the kernel at it
+ * instead of evaluating the launch's values on the host (tdv::single_pass strategies, hip/StencilUpdate.hpp). */
+int ststhip_current_tdv_table(const void **base, uint64_t *first_iteration, uint64_t *n_values,
+                              uint64_t *value_size);
 /* A host that runs row-range sweeps side by side itself (the multi-GPU strip driver,
  * stencilstream_amd/dist.py) states their number here for the calling thread; 1 resets it. */
 int ststhip_set_launch_concurrency(int n_launches_side_by_side);
@@ -244,6 +250,13 @@ typedef struct {
     uint32_t halo_depth_per_generation; /* radius * n_subiterations */
     uint32_t strip_width;               /* columns one wave produces at max_generations (0 = unknown) */
     uint64_t plane_elem_size[16];
+    /* Time-dependent values (0 / NULL: the sweep callback provides them per launch).  The driver builds ONE device
+     * table per call -- element i = value of generation iteration_offset + i -- either by calling fill_tdv (host
+     * evaluation, once per generation as the reference's backends do, cuda/StencilUpdate.hpp:224) and uploading
+     * it, or by taking `tdv_device_table` (n_iterations values the caller has already computed on the device). */
+    uint64_t tdv_size;
+    void (*fill_tdv)(void *ctx, uint64_t iteration_offset, uint64_t n_iterations, void *values);
+    const void *tdv_device_table;
 } ststhip_sweep_desc;
 int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc,
                        const ststhip_domain *dom, const void *const *src, void *const *dst,
@@ -254,6 +267,9 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
 typedef struct {
     float coef[9]; /* as many as the variant takes; Jacobi9General: coef[r*3+c] */
 } ststhip_jacobi_params;
+typedef struct {
+    float coef[25]; /* "jacobi25general": dense 5 x 5, radius 2, coef[(dr+2)*5 + (dc+2)] */
+} ststhip_jacobi25_params;
 typedef struct {
     float Rx_1, Ry_1, Rz_1, Cap_1;
 } ststhip_hotspot_params;

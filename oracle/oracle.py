@@ -136,6 +136,17 @@ def jacobi(variant, coef, grid, n_iterations, halo=0.0, iteration_offset=0, n_th
     return out
 
 
+def jacobi25(coef, grid, n_iterations, halo=0.0, n_threads=1):
+    """Dense 5 x 5 Jacobi of radius 2 (an extra: SURVEY 8(f)4), coef[(dr+2)*5 + (dc+2)]."""
+    src = np.ascontiguousarray(grid, dtype=np.float32)
+    out = np.empty_like(src)
+    cf = np.ascontiguousarray(coef, dtype=np.float32).reshape(25)
+    rc = lib().oracle_jacobi25(_p(cf), _p(src), _p(out), _sz(src.shape[0]), _sz(src.shape[1]), C.c_float(halo),
+                               _sz(n_iterations), C.c_int(n_threads))
+    assert rc == 0
+    return out
+
+
 def jacobi_init(H, W):
     g = np.empty((H, W), dtype=np.float32)
     lib().oracle_jacobi_init(_p(g), _sz(H), _sz(W))

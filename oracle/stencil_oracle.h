@@ -92,6 +92,9 @@ enum {
 int oracle_jacobi(int variant, const float *coef, const float *in, float *out, size_t H,
                   size_t W, float halo, size_t iteration_offset, size_t n_iterations,
                   int n_threads);
+/* dense 5 x 5 Jacobi, radius 2 (an extra, see stencil_oracle.c); coef[(dr+2)*5 + (dc+2)] */
+int oracle_jacobi25(const float *coef, const float *in, float *out, size_t H, size_t W, float halo,
+                    size_t n_iterations, int n_threads);
 /* grid init of examples/jacobi/jacobi.cpp:111-124 */
 void oracle_jacobi_init(float *grid, size_t H, size_t W);
 

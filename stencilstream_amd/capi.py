@@ -77,6 +77,12 @@ class JacobiParams(C.Structure):
     _fields_ = [("coef", C.c_float * 9)]
 
 
+class Jacobi25Params(C.Structure):
+    """ststhip_jacobi25_params: dense 5 x 5 Jacobi of radius 2"""
+
+    _fields_ = [("coef", C.c_float * 25)]
+
+
 class JacobiUniformParams(C.Structure):
     """parameter block of the jacobi5uniform* kernels: the common coefficient"""
 

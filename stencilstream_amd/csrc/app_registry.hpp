@@ -18,6 +18,9 @@ struct AppEntry {
                  const void *const *src, void *const *dst, std::uint64_t out_begin,
                  std::uint64_t out_end, std::uint64_t iteration, std::uint32_t n_generations,
                  ststhip_stream stream);
+    // values of generations [iteration_offset, iteration_offset + n) into `values` (n * info.tdv_size bytes),
+    // evaluated on the host; nullptr for functions without a time-dependent value
+    void (*fill_tdv)(const void *tf_params, std::uint64_t iteration_offset, std::uint64_t n, void *values);
 };
 
 void register_app(AppEntry const &entry);
@@ -41,15 +44,20 @@ template <typename F, bool SOA> struct AppAdapter {
             const F f = F::from_params(block);
             Cell halo;
             std::memcpy(static_cast<void *>(&halo), halo_cell, sizeof(Cell));
+            // a single launch through ststhip_app_sweep: the launch's values, evaluated here; inside
+            // ststhip_app_run the pass driver has put the whole call's values into a device table
             TDV tdv[Tuning::max_generations];
-            for (std::uint32_t t = 0; t < n_generations && t < std::uint32_t(Tuning::max_generations); t++)
-                tdv[t] = f.get_time_dependent_value(iteration + t);
+            const void *table = nullptr;
+            ststhip_current_tdv_table(&table, nullptr, nullptr, nullptr);
+            if (!table)
+                for (std::uint32_t t = 0; t < n_generations && t < std::uint32_t(Tuning::max_generations); t++)
+                    tdv[t] = f.get_time_dependent_value(iteration + t);
             Planes s, d;
             for (int i = 0; i < Planes::n_planes; i++) {
                 s.plane[i] = const_cast<void *>(src[i]);
                 d.plane[i] = dst[i];
             }
-            stencil::hip::internal::dispatch_sweep<F, SOA>(int(n_generations), f, halo, tdv, *dom,
+            stencil::hip::internal::dispatch_sweep<F, SOA>(int(n_generations), f, halo, table ? nullptr : tdv, *dom,
                                                            s, d, out_begin, out_end, iteration,
                                                            stream);
             return STSTHIP_OK;
@@ -57,6 +65,16 @@ template <typename F, bool SOA> struct AppAdapter {
             return e.status; // message already recorded by the failing runtime call
         } catch (std::exception const &e) {
             return fail(STSTHIP_ERR_INVALID, e.what());
+        }
+    }
+
+    static void fill_tdv(const void *tf_params, std::uint64_t iteration_offset, std::uint64_t n, void *values) {
+        typename F::Block block;
+        std::memcpy(&block, tf_params, sizeof block);
+        const F f = F::from_params(block);
+        for (std::uint64_t i = 0; i < n; i++) {
+            const TDV v = f.get_time_dependent_value(iteration_offset + i);
+            std::memcpy(static_cast<unsigned char *>(values) + i * sizeof(TDV), &v, sizeof(TDV));
         }
     }
 
@@ -81,6 +99,7 @@ template <typename F, bool SOA> struct AppAdapter {
         e.info.prefetch_rows = std::uint32_t(Tuning::prefetch_rows);
         e.info.cooperative = stencil::hip::internal::cooperative_for<F, SOA>() ? 1u : 0u;
         e.sweep = &sweep;
+        e.fill_tdv = e.info.tdv_size ? &fill_tdv : nullptr;
         return e;
     }
 };

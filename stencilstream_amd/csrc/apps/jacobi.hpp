@@ -63,6 +63,37 @@ template <JacobiVariant V> struct Jacobi : public BaseTransitionFunction {
     }
 };
 
+// A dense 5 x 5 Jacobi of radius 2: Jacobi9General's loop (kernels.hpp:307-318) over a radius-2 stencil.  Not an
+// application of the reference (SURVEY 8(f)4 asks for a tuned radius > 1 kernel); it exercises the radius-2
+// stencil indexing (Stencil.hpp:120-146) and two-cell halos in the sweep.
+struct Jacobi25 {
+    using Cell = float;
+    using TimeDependentValue = std::monostate;
+    using Block = ststhip_jacobi25_params;
+    static constexpr std::size_t stencil_radius = 2;
+    static constexpr std::size_t n_subiterations = 1;
+
+    float coef[25];
+
+    static Jacobi25 from_params(Block const &p) {
+        Jacobi25 j;
+        for (int i = 0; i < 25; i++)
+            j.coef[i] = p.coef[i];
+        return j;
+    }
+    STST_HD std::monostate get_time_dependent_value(std::size_t) const { return {}; }
+
+    STST_HD float operator()(Stencil<float, 2> const &s) const {
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = -2; r <= 2; r++)
+#pragma unroll
+            for (int c = -2; c <= 2; c++)
+                sum += coef[(r + 2) * 5 + (c + 2)] * s[r][c];
+        return sum;
+    }
+};
+
 } // namespace apps
 } // namespace stencil
 
@@ -124,6 +155,16 @@ template <bool FirstLaunch, bool LastLaunch> struct Jacobi5Uniform : public Base
 
 namespace hip {
 template <typename F, bool SOA> struct SweepTuning;
+// The dense 3 x 3 (17 flops and six lane shifts per cell) is bound by its instructions at any depth; four
+// generations per launch leave the fewest warm-up rows and halo columns that HBM still hides
+// (profiles/r02_tune_radius.txt, 16384^2: K=4 T=8: 1815, T=4: 1947, K=3 T=8: 1733, K=2 T=8: 1630, K=3 T=12: 1623).
+template <> struct SweepTuning<apps::Jacobi<apps::JacobiVariant::General9>, false> {
+    static constexpr int cells_per_lane = 4;
+    static constexpr int max_generations = 4;
+    static constexpr int prefetch_rows = 4;
+    static constexpr bool interior_variant = true;
+    static constexpr int min_waves_per_simd = 1;
+};
 // With 5 flops per cell the kernel is HBM bound at 8 generations per launch; 12 generations on 3 cells
 // per lane is the measured optimum (profiles/r01_tune_jacobi_uniform.txt: K=4,T=8: 4.4, K=2,T=16: 5.1,
 // K=4,T=12: 5.3, K=3,T=12: 5.5, K=3,T=16: 5.0 Tcell/s).  Launch depths: 12 and its halvings 6, 3, 1.

@@ -695,6 +695,21 @@ int ststhip_occupancy(const void *function, unsigned block_threads, size_t share
     return STSTHIP_OK;
 }
 
+static thread_local const void *g_tdv_table = nullptr;
+static thread_local std::uint64_t g_tdv_first = 0, g_tdv_count = 0, g_tdv_size = 0;
+int ststhip_current_tdv_table(const void **base, uint64_t *first_iteration, uint64_t *n_values,
+                              uint64_t *value_size) {
+    if (base)
+        *base = g_tdv_table;
+    if (first_iteration)
+        *first_iteration = g_tdv_first;
+    if (n_values)
+        *n_values = g_tdv_count;
+    if (value_size)
+        *value_size = g_tdv_size;
+    return STSTHIP_OK;
+}
+
 static thread_local int g_launch_concurrency = 1;
 static thread_local int g_target_holds_constants = 0;
 int ststhip_launch_concurrency(void) { return g_launch_concurrency; }
@@ -935,6 +950,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
     std::uint64_t n_launches = 0;
     int rc = STSTHIP_OK;
     void *scratch[16] = {nullptr};
+    void *tdv_table = nullptr;
     // events and stream waits carry the ordering between strips: a failure there must fail the run
     auto ordered = [&](hipError_t err, const char *what) {
         if (err != hipSuccess && rc == STSTHIP_OK)
@@ -954,6 +970,25 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             for (unsigned p = 0; p < n_planes && rc == STSTHIP_OK; p++)
                 rc = ststhip_malloc_async(&scratch[p], plane_cells * desc->plane_elem_size[p], s);
 
+        // one device table of time-dependent values for the whole call
+        if (rc == STSTHIP_OK && desc->tdv_size > 0 && (desc->fill_tdv || desc->tdv_device_table)) {
+            const std::size_t bytes = std::size_t(desc->tdv_size) * n_iterations;
+            if (desc->tdv_device_table) {
+                g_tdv_table = desc->tdv_device_table;
+            } else {
+                rc = ststhip_malloc_async(&tdv_table, bytes, s);
+                if (rc == STSTHIP_OK) {
+                    std::vector<unsigned char> values(bytes);
+                    desc->fill_tdv(ctx, iteration_offset, n_iterations, values.data());
+                    // pageable source: the copy is staged before the call returns
+                    ordered(hipMemcpyAsync(tdv_table, values.data(), bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync");
+                    g_tdv_table = tdv_table;
+                }
+            }
+            g_tdv_first = iteration_offset;
+            g_tdv_count = n_iterations;
+            g_tdv_size = desc->tdv_size;
+        }
         auto new_event = [&]() {
             hipEvent_t e = nullptr;
             ordered(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
@@ -1041,6 +1076,8 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         }
         g_launch_concurrency = 1;
         g_target_holds_constants = 0;
+        g_tdv_table = nullptr;
+        g_tdv_count = 0;
         // join: the caller's stream continues after every strip has finished
         for (int v = 1; v < strips; v++) {
             hipEvent_t done = new_event();
@@ -1058,6 +1095,8 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
     for (unsigned p = 0; p < n_planes; p++)
         if (scratch[p])
             ststhip_free_async(scratch[p], s);
+    if (tdv_table)
+        ststhip_free_async(tdv_table, s);
     double kernel_s = 0.0;
     for (auto &ev : timed) {
         float ms = 0.0f;
@@ -1103,6 +1142,11 @@ int uniform_jacobi_trampoline(void *ctx, const ststhip_domain *dom, const void *
         float c;
     } block = {call->c};
     return entry->sweep(&block, call->halo_cell, dom, src, dst, out_begin, out_end, iteration, n_generations, stream);
+}
+
+void app_fill_tdv(void *ctx, uint64_t iteration_offset, uint64_t n_iterations, void *values) {
+    const AppCall *call = static_cast<const AppCall *>(ctx);
+    call->entry->fill_tdv(call->tf_params, iteration_offset, n_iterations, values);
 }
 
 int app_sweep_trampoline(void *ctx, const ststhip_domain *dom, const void *const *src, void *const *dst,
@@ -1201,6 +1245,10 @@ int resolve_app(ResolvedApp &r, const char *app, const void *tf_params, const vo
         r.call = AppCall{e, tf_params, r.packed ? static_cast<const void *>(&r.dead_word) : halo_cell};
         r.trampoline = app_sweep_trampoline;
         r.ctx = &r.call;
+        if (e->fill_tdv) { // one device table of time-dependent values per call
+            r.desc.tdv_size = e->info.tdv_size;
+            r.desc.fill_tdv = app_fill_tdv;
+        }
     }
     return STSTHIP_OK;
 }

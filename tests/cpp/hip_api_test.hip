@@ -3,9 +3,11 @@
 // for the reference look; it is device-callable because this file is built with --hipstdpar.
 #include "api_tests.hpp"
 #include <StencilStream/BaseTransitionFunction.hpp>
+#include <StencilStream/cpu/StencilUpdate.hpp>
 #include <StencilStream/cuda/StencilUpdate.hpp>
 #include <StencilStream/cuda/internal/Helpers.hpp>
 #include <apps/conway.hpp>
+#include <cstdio>
 #include <cstring>
 
 using namespace stencil;
@@ -206,7 +208,66 @@ static void test_field_buffers() {
     REQUIRE(set.plane[0] == std::get<0>(buffers.pointers()) && set.plane[4] == std::get<4>(buffers.pointers()));
 }
 
+// A function with a time-dependent value and two sub-iterations, exact in fp32 whatever evaluates it (host libm,
+// device, inline): the three tdv::single_pass strategies must give the cpu backend's result bit for bit.
+struct Ramp {
+    using Cell = float;
+    using TimeDependentValue = float;
+    static constexpr std::size_t stencil_radius = 1;
+    static constexpr std::size_t n_subiterations = 2;
+    float gain;
+    float get_time_dependent_value(std::size_t i) const { return float(i % 7) * gain; }
+    float operator()(Stencil<float, 1, float> const &s) const {
+        if (s.subiteration == 0)
+            return 0.5f * (s[0][-1] + s[0][1]) + s.time_dependent_value;
+        return 0.5f * (s[-1][0] + s[1][0]) - 0.25f * s.time_dependent_value + float(s.iteration % 3);
+    }
+};
+
+template <typename Strategy> static void test_tdv_strategy(const char *name) {
+    const std::size_t h = 200, w = 333, offset = 5;
+    using SU = hip::StencilUpdate<Ramp, false, Strategy>;
+    using Reference = cpu::StencilUpdate<Ramp>;
+    static_assert(tdv::single_pass::Strategy<Strategy, Ramp, 8>);
+    hip::Grid<float> grid(h, w);
+    cpu::Grid<float> host_grid(h, w);
+    {
+        hip::Grid<float>::GridAccessor<sycl::access::mode::read_write> ac(grid);
+        cpu::Grid<float>::GridAccessor<sycl::access::mode::read_write> hc(host_grid);
+        for (std::size_t r = 0; r < h; r++)
+            for (std::size_t c = 0; c < w; c++)
+                hc[r][c] = ac[r][c] = float((r * 13 + c * 7) % 64) * 0.125f;
+    }
+    // 29 generations = launches of every compiled depth; a second call resumes at the new offset
+    SU update({.transition_function = Ramp{0.5f}, .halo_value = 1.0f, .iteration_offset = offset, .n_iterations = 29,
+               .blocking = true});
+    Reference reference({.transition_function = Ramp{0.5f}, .halo_value = 1.0f, .iteration_offset = offset,
+                         .n_iterations = 29, .blocking = true});
+    hip::Grid<float> out = update(grid);
+    cpu::Grid<float> want = reference(host_grid);
+    update.get_params().iteration_offset = reference.get_params().iteration_offset = offset + 29;
+    update.get_params().n_iterations = reference.get_params().n_iterations = 4;
+    out = update(out);
+    want = reference(want);
+    hip::Grid<float>::GridAccessor<sycl::access::mode::read> ac(out);
+    cpu::Grid<float>::GridAccessor<sycl::access::mode::read> wc(want);
+    bool same = true;
+    for (std::size_t r = 0; r < h; r++)
+        for (std::size_t c = 0; c < w; c++)
+            same = same && std::memcmp(&ac[r][c], &wc[r][c], sizeof(float)) == 0;
+    if (!same)
+        std::fprintf(stderr, "strategy %s differs from the cpu backend\n", name);
+    REQUIRE(same);
+}
+
+static void test_tdv_strategies() {
+    test_tdv_strategy<tdv::single_pass::PrecomputeOnHostStrategy>("PrecomputeOnHost");
+    test_tdv_strategy<tdv::single_pass::PrecomputeOnDeviceStrategy>("PrecomputeOnDevice");
+    test_tdv_strategy<tdv::single_pass::InlineStrategy>("Inline");
+}
+
 int main() {
+    test_tdv_strategies();
     test_field_buffers();
     api_tests::test_stencil_indexing();
     api_tests::test_grid<hip::Grid<sycl::id<2>>>(128, 128);

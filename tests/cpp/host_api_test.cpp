@@ -2,6 +2,8 @@
 #include "api_tests.hpp"
 #include <StencilStream/BaseTransitionFunction.hpp>
 #include <StencilStream/cpu/StencilUpdate.hpp>
+#include <StencilStream/tdv/SinglePassStrategies.hpp>
+#include <algorithm>
 #include <apps/conway.hpp>
 #include <nlohmann/json.hpp>
 #include <sstream>
@@ -84,7 +86,44 @@ static void test_ac_int() {
     REQUIRE(table[idx] == 3);
 }
 
+// The strategy protocol of the reference (tdv/SinglePassStrategies.hpp:44-112: GlobalState -> KernelArgument ->
+// LocalState) walked on the host for all three strategies: the value of the pass's i-th iteration.
+struct Wave {
+    using Cell = int;
+    using TimeDependentValue = long;
+    static constexpr std::size_t stencil_radius = 1, n_subiterations = 1;
+    long scale;
+    long get_time_dependent_value(std::size_t i) const { return scale * long(i) + 3; }
+    int operator()(Stencil<int, 1, long> const &s) const { return s[0][0]; }
+};
+
+template <typename S> static void walk_strategy() {
+    using namespace stencil::tdv::single_pass;
+    static_assert(Strategy<S, Wave, 4>);
+    using Global = typename S::template GlobalState<Wave, 4>;
+    Global global(Wave{10}, /*iteration_offset=*/100, /*n_iterations=*/10);
+    for (std::size_t pass = 100; pass < 110; pass += 4) {
+        const std::size_t n = std::min<std::size_t>(4, 110 - pass);
+        typename Global::KernelArgument argument = [&] {
+            if constexpr (S::kind == Kind::PrecomputeOnHost)
+                return typename Global::KernelArgument(global, pass, n);
+            else
+                return typename Global::KernelArgument(global, pass);
+        }();
+        typename Global::KernelArgument::LocalState local(argument);
+        for (std::size_t i = 0; i < n; i++)
+            REQUIRE(local.get_time_dependent_value(i) == 10 * long(pass + i) + 3);
+    }
+}
+
+static void test_tdv_strategy_protocol() {
+    walk_strategy<stencil::tdv::single_pass::InlineStrategy>();
+    walk_strategy<stencil::tdv::single_pass::PrecomputeOnDeviceStrategy>();
+    walk_strategy<stencil::tdv::single_pass::PrecomputeOnHostStrategy>();
+}
+
 int main() {
+    test_tdv_strategy_protocol();
     api_tests::test_stencil_indexing();
     api_tests::test_grid<cpu::Grid<sycl::id<2>>>(128, 128);
     api_tests::test_grid<cpu::Grid<sycl::id<2>>>(3, 17);
