@@ -552,6 +552,13 @@ struct Sweep {
             return cell;
         };
 
+        // The launch's time-dependent values: the call's device table, or the kernel arguments.  Both are read
+        // through the constant address space -- nothing writes them while the kernel runs --, so the compiler may
+        // load a value again wherever it needs it instead of holding T scalar registers over the row loop (a plain
+        // global load could not be moved over the loop's stores at all).
+        using ConstantTDV = const TDV __attribute__((address_space(4)));
+        ConstantTDV *launch_tdv = a.tdv_table ? (ConstantTDV *)(a.tdv_table) : (ConstantTDV *)(a.tdv);
+
         Cell win[S][NWIN][K]; // level l-1's older rows, rotating
         Cell pre[P][K];       // rows in flight from HBM
         static_for<0, S>([&](auto l) __attribute__((always_inline)) {
@@ -660,7 +667,7 @@ struct Sweep {
                         else if constexpr (INLINE_TDV)
                             return a.f.get_time_dependent_value(iteration);
                         else
-                            return a.tdv_table ? a.tdv_table[(level - 1) / NS] : a.tdv[(level - 1) / NS];
+                            return launch_tdv[(level - 1) / NS];
                     }();
 
                     // rows j-R .. j+R of the previous level, widened by R cells from both neighbour lanes
