@@ -77,10 +77,84 @@ struct Fdtd {
     }
 };
 
+// The same cell as two 16-byte halves -- what the update changes, and the material coefficients it only copies --
+// and the same update on it.  Swept on planes this gives TWO planes of 16-byte elements instead of eight of 4:
+// every access is one full-width vector per lane, and the coefficient plane is read but never written again
+// (constant_fields), which the 32-byte AoS cell cannot offer (a half-written cell costs the same transaction) and
+// the eight thin planes pay for with misaligned 160-byte strips.  The bytes of a cell are those of FdtdCell /
+// the reference's CoefCell (material/CoefResolver.hpp:24-31), so AoS grids interchange.
+struct FdtdFields {
+    float ex, ey, hz, hz_sum;
+};
+struct FdtdMaterial {
+    float ca, cb, da, db;
+};
+struct FdtdGroupedCell {
+    FdtdFields f;
+    FdtdMaterial m;
+    static constexpr auto fields = std::make_tuple(&FdtdGroupedCell::f, &FdtdGroupedCell::m);
+};
+static_assert(sizeof(FdtdGroupedCell) == sizeof(FdtdCell));
+
+struct FdtdGrouped {
+    using Cell = FdtdGroupedCell;
+    using TimeDependentValue = float;
+    using Block = ststhip_fdtd_params;
+    static constexpr std::size_t stencil_radius = 1;
+    static constexpr std::size_t n_subiterations = 2;
+
+    Block p;
+
+    static constexpr auto constant_fields = std::make_tuple(&FdtdGroupedCell::m);
+
+    static FdtdGrouped from_params(Block const &block) { return FdtdGrouped{block}; }
+    float get_time_dependent_value(std::size_t i_iteration) const { return Fdtd{p}.get_time_dependent_value(i_iteration); }
+
+    // Kernel.hpp:86-128, expression for expression as in Fdtd::operator() above
+    STST_HD Cell operator()(Stencil<Cell, 1, float> const &s) const {
+        Cell cell = s[0][0];
+        const float r = s.id[0];
+        const float c = s.id[1];
+        const float source_distance_score = r * (r - 2 * p.source_r) + c * (c - 2 * p.source_c);
+
+        if (s.subiteration == 0) {
+            cell.f.ex *= cell.m.ca;
+            cell.f.ex += cell.m.cb * (s[0][0].f.hz - s[0][-1].f.hz);
+            cell.f.ey *= cell.m.ca;
+            cell.f.ey += cell.m.cb * (s[-1][0].f.hz - s[0][0].f.hz);
+        } else {
+            cell.f.hz *= cell.m.da;
+            cell.f.hz += cell.m.db * (s[0][1].f.ex - s[0][0].f.ex + s[0][0].f.ey - s[1][0].f.ey);
+
+            if (source_distance_score <= p.source_distance_bound && s.iteration <= p.cutoff_iteration) {
+                float interp_factor;
+                if (p.source_radius_squared != 0) {
+                    float cell_distance_squared =
+                        source_distance_score + p.source_c * p.source_c + p.source_r * p.source_r;
+                    interp_factor = 1.0 - float(cell_distance_squared) / p.source_radius_squared;
+                } else {
+                    interp_factor = 1.0;
+                }
+                cell.f.hz += interp_factor * s.time_dependent_value;
+            }
+            if (s.iteration > p.detect_iteration)
+                cell.f.hz_sum += cell.f.hz * cell.f.hz;
+        }
+        return cell;
+    }
+};
+
 } // namespace apps
 
 namespace hip {
 template <typename F, bool SOA> struct SweepTuning;
+template <bool SOA> struct SweepTuning<apps::FdtdGrouped, SOA> {
+    static constexpr int cells_per_lane = 1;
+    static constexpr int max_generations = 6;
+    static constexpr int prefetch_rows = 2;
+    static constexpr bool interior_variant = true;
+    static constexpr int min_waves_per_simd = 1;
+};
 // Measured (profiles/r01_tune_shapes_apps.txt, 4608^2): K=1 with T=4,P=4: 270 / 231 (AoS / planes),
 // T=5,P=2: 314 / 244, T=6,P=2: 347 / 284, T=7,P=2: 234 (register cliff) Gcell/s.  Launch depths 6, 3, 1.
 template <bool SOA> struct SweepTuning<apps::Fdtd, SOA> {

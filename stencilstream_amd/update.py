@@ -62,8 +62,13 @@ def selfcheck(radius=1, split_cell_structure=False):
     return TransitionFunction(name, capi.NoParams(), SELFCHECK_CELL)
 
 
-def fdtd(params, split_cell_structure=True):
-    return TransitionFunction("fdtd_coef" if split_cell_structure else "fdtd_coef_aos", params, FDTD_CELL)
+def fdtd(params, split_cell_structure=True, layout=None):
+    """layout: "grouped" (two planes of 16 bytes: fields / material coefficients; the fastest, default for a split
+    request), "planes" (one plane per field, the reference's SoA protocol) or "aos"."""
+    if layout is None:
+        layout = "grouped" if split_cell_structure else "aos"
+    app = {"grouped": "fdtd_coef_grouped", "planes": "fdtd_coef", "aos": "fdtd_coef_aos"}[layout]
+    return TransitionFunction(app, params, FDTD_CELL)
 
 
 class Grid:

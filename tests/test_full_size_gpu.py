@@ -203,3 +203,11 @@ def test_fdtd_max_grid_full_size_windows(gpu, oracle, where):
                  blocking=True, stream=s.cuda_stream)
     for f in range(8):
         assert torch.equal(outs[f], out[..., f]), f"planes and AoS sweeps differ in field {f}"
+
+    # two planes of 16-byte halves (fields / material coefficients; the coefficient plane is not stored again)
+    halves = [cells[..., :4].contiguous(), cells[..., 4:].contiguous()]
+    outs = [torch.empty_like(h) for h in halves]
+    torch.cuda.synchronize()
+    capi.app_run("fdtd_coef_grouped", pc, halo, dom, [h.data_ptr() for h in halves], [h.data_ptr() for h in outs], offset,
+                 n, blocking=True, stream=s.cuda_stream)
+    assert torch.equal(outs[0], out[..., :4]) and torch.equal(outs[1], out[..., 4:]), "grouped planes and AoS sweeps differ"

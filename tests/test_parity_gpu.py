@@ -190,15 +190,17 @@ def fdtd_setup(oracle, H, W):
     return po, pc, cells
 
 
-@pytest.mark.parametrize("split", [True, False], ids=["soa", "aos"])
+@pytest.mark.parametrize("layout", ["grouped", "planes", "aos"])
 @pytest.mark.parametrize("shape", [(162, 162), (40, 333)], ids=str)
-def test_fdtd_bit_exact(gpu, oracle, shape, split):
+def test_fdtd_bit_exact(gpu, oracle, shape, layout):
+    """Three layouts of the same sweep: two planes of 16-byte halves (fields / material coefficients, the latter
+    never stored again), one plane per field (the reference's SoA protocol), AoS cells."""
     from stencilstream_amd import update as U
 
     po, pc, cells = fdtd_setup(oracle, *shape)
     halo = np.zeros((), dtype=U.FDTD_CELL)
     for n, offset in ((1, 0), (7, 0), (30, 5), (25, 30)):
-        got = run_hip(U.fdtd(pc, split), cells, n, halo=halo, offset=offset)
+        got = run_hip(U.fdtd(pc, layout=layout), cells, n, halo=halo, offset=offset)
         want = oracle.fdtd(po, cells, n, iteration_offset=offset, n_threads=8)
         assert np.array_equal(bits(got), bits(want)), f"n={n} offset={offset}"
     assert np.abs(want["hz_sum"]).max() > 0 and np.abs(want["hz"]).max() > 0

@@ -21,7 +21,7 @@ from bench_apps import hotspot_params
 
 FAMILIES = {
     # family: (grid, params, value ranges per field, baseline, candidates)
-    "fdtd": (4608, "fdtd", ["fdtd_coef_aos", "fdtd_coef"],
+    "fdtd": (4608, "fdtd", ["fdtd_coef_aos", "fdtd_coef", "fdtd_coef_grouped"],
              ["x_fd_aos_k1t6_coop", "x_fd_soa_k1t6_coop", "x_fd_aos_k1t4_coop", "x_fd_aos_k1t8_coop",
               "x_fd_aos_k1t6_coop_nobarrier", "x_fd_aos_k1t6_coop_nolds", "x_fd_aos_k1t6_coop_neither",
               "x_fd_aos_k1t6p4", "x_fd_aos_k1t6p6", "x_fd_aos_k1t6p8", "x_fd_aos_k1t4p8"]),
@@ -70,13 +70,21 @@ def buffers(app, field_list):
     info = capi.app_info(app)
     if info.n_planes == 1 and len(field_list) > 1:
         src = [torch.stack(field_list, dim=-1).contiguous()]
+    elif info.n_planes != len(field_list):  # planes of several fields each (equal group sizes)
+        per = len(field_list) // info.n_planes
+        src = [torch.stack(field_list[g * per:(g + 1) * per], dim=-1).contiguous() for g in range(info.n_planes)]
     else:
         src = [f.clone() for f in field_list]
     return info, src, [torch.empty_like(t) for t in src]
 
 
 def as_fields(info, planes, n_fields):
-    return [planes[0][..., i] for i in range(n_fields)] if (info.n_planes == 1 and n_fields > 1) else planes
+    if info.n_planes == 1 and n_fields > 1:
+        return [planes[0][..., i] for i in range(n_fields)]
+    if info.n_planes != n_fields:
+        per = n_fields // info.n_planes
+        return [planes[g][..., i] for g in range(info.n_planes) for i in range(per)]
+    return planes
 
 
 def main():

@@ -52,7 +52,7 @@ def run(app, params, halo, planes_a, planes_b, H, W, gens, stream, reps=3):
 
 def main():
     which = sys.argv[1:] or ["jacobi", "hotspot", "hotspot_aos", "hotspot_f64", "hotspot_f64_aos", "fdtd", "fdtd_aos",
-                             "conway"]
+                             "fdtd_grouped", "conway"]
     if which == ["experiments"]:
         which = ["hotspot", "fdtd", "fdtd_aos", "conway"] + [a for a in capi.list_apps() if a.startswith(("x_hs_", "x_fd_", "x_cw_"))]
     capi.init(0)
@@ -101,8 +101,8 @@ def main():
                 cells = torch.zeros(H, W, 2, device=dev, dtype=torch.float64)
                 cells[..., 0] = 30.0
                 pa, pb = [cells], [torch.empty_like(cells)]
-        elif name in ("fdtd", "fdtd_aos"):
-            app, H, W, gens = ("fdtd_coef" if name == "fdtd" else "fdtd_coef_aos"), 4608, 4608, 120
+        elif name in ("fdtd", "fdtd_aos", "fdtd_grouped"):
+            app, H, W, gens = {"fdtd": "fdtd_coef", "fdtd_aos": "fdtd_coef_aos", "fdtd_grouped": "fdtd_coef_grouped"}[name], 4608, 4608, 120
             p = capi.FdtdParams(dt=8.1e-19, t_0=3e-13, tau=1e-13, omega=7.5e14, cutoff_iteration=10 ** 9,
                                 detect_iteration=0, source_radius_squared=100.0, source_r=H / 2, source_c=W / 2,
                                 source_distance_bound=100.0 - 2 * (H / 2) ** 2, double_center_rc=float(H))
@@ -110,6 +110,12 @@ def main():
             if name == "fdtd":
                 pa = [torch.rand(H, W, device=dev) * 1e-3 for _ in range(4)] + [torch.full((H, W), v, device=dev) for v in (1.0, 0.3, 1.0, 0.3)]
                 pb = [torch.empty(H, W, device=dev) for _ in range(8)]
+            elif name == "fdtd_grouped":
+                material = torch.empty(H, W, 4, device=dev)
+                for i, v in enumerate((1.0, 0.3, 1.0, 0.3)):
+                    material[..., i] = v
+                pa = [torch.rand(H, W, 4, device=dev) * 1e-3, material]
+                pb = [torch.empty_like(t) for t in pa]
             else:
                 cells = torch.rand(H, W, 8, device=dev) * 1e-3
                 pa, pb = [cells], [torch.empty_like(cells)]
