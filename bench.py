@@ -328,12 +328,37 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    strips_verified = None
     if world > 1:
         import torch.distributed as dist
 
         t = torch.tensor([elapsed], device="cpu" if args.debug_host_exchange else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if not args.no_verify:
+            # every rank checks the bulk of its own rows of the last step's result: exact scalar recurrence further
+            # than `gens` cells inside the square, +0 further than `gens` cells outside it (verify() has the argument)
+            # (the strips' state has advanced through warm-up and timed steps; the check runs one more step from
+            # the initial grid, outside the timed region)
+            if native:
+                strip.upload_from_device(0, init.data_ptr(), init.numel() * init.element_size())
+                strip.advance(0, gens, blocking=True)
+                rows = torch.from_numpy(strip.download(0, np.float32))
+            else:
+                strip.load_owned(init)
+                strip.advance(0, gens)
+                rows = strip.owned(0, torch.float32).cpu()
+            r = torch.arange(a, b)[:, None]
+            c = torch.arange(W)[None, :]
+            lo_r, hi_r, lo_c, hi_c = total_rows // 4, 3 * total_rows // 4, W // 4, 3 * W // 4
+            inside = (r >= lo_r + gens) & (r < hi_r - gens) & (c >= lo_c + gens) & (c < hi_c - gens)
+            outside = (r < lo_r - gens) | (r >= hi_r + gens) | (c < lo_c - gens) | (c >= hi_c + gens)
+            want = float(uniform_field_value(gens))
+            ok = bool((rows[inside.expand_as(rows)] == want).all()) and \
+                bool((rows.view(torch.int32)[outside.expand_as(rows)] == 0).all())
+            flag = torch.tensor([1 if ok else 0], device="cpu" if args.debug_host_exchange else device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            strips_verified = bool(flag.item())
 
     if rank == 0:
         cells = total_rows * W * gens * args.steps
@@ -366,6 +391,11 @@ def main():
         }
         if ranks_report:
             out["ranks"] = ranks_report
+        if strips_verified is not None:
+            out["verified"] = strips_verified
+            out["verification"] = {"what": "every rank: the bulk of its rows of the last step against the exact scalar "
+                                           "recurrence inside the square and +0 outside it (all cells further than the "
+                                           "generations per step from the rim of the square)"}
         if world == 1 and not args.strip_domain:
             if not args.no_verify:
                 ok, report = verify(torch, capi, app, p, halo, dom, src, dst, gens, stream, total_rows, W)
