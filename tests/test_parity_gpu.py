@@ -946,3 +946,45 @@ def test_narrow_form_equals_default_shape(gpu, oracle, monkeypatch):
         want = oracle.jacobi("Jacobi5General", coef, src.cpu().numpy(), 29, halo=halo, n_threads=8)
         for out in outs:
             assert np.array_equal(bits(out.cpu().numpy()), bits(want))
+
+
+def test_pool_hands_blocks_over_in_stream_order(gpu):
+    """ststhip_free_async: a block released while work is queued on stream A goes to stream A again at once, and to
+    stream B only behind the release event (the stream-agnostic free list was a data race)."""
+    import ctypes as C
+
+    import torch
+
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    lib = capi.load()
+    n = 512 << 20
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    capi.check(lib.ststhip_stream_create(C.byref(s1)), "stream")
+    capi.check(lib.ststhip_stream_create(C.byref(s2)), "stream")
+    p, q, r = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    capi.check(lib.ststhip_malloc_async(C.byref(p), n, s1), "malloc")
+    for _ in range(8):  # a queue of work on s1 that still uses the block when it is released
+        capi.check(lib.ststhip_memset(p, 1, n, s1), "memset")
+    capi.check(lib.ststhip_free_async(p, s1), "free")
+    capi.check(lib.ststhip_malloc_async(C.byref(q), n, s2), "malloc")  # the same bucket: the block comes back
+    assert q.value == p.value
+    capi.check(lib.ststhip_memset(q, 2, n, s2), "memset")  # must land after the eight memsets of s1
+    capi.check(lib.ststhip_stream_synchronize(s2), "sync")
+    capi.check(lib.ststhip_stream_synchronize(s1), "sync")
+    host = torch.empty(n, dtype=torch.uint8)
+    capi.check(lib.ststhip_memcpy_d2h(C.c_void_p(host.data_ptr()), q, n, s2), "d2h")
+    capi.check(lib.ststhip_stream_synchronize(s2), "sync")
+    assert int(host.min()) == 2 and int(host.max()) == 2
+    # host-ordered allocation of a block whose release event is pending: waits for it, then owns it
+    capi.check(lib.ststhip_memset(q, 3, n, s2), "memset")
+    capi.check(lib.ststhip_free_async(q, s2), "free")
+    capi.check(lib.ststhip_malloc(C.byref(r), n), "malloc")
+    assert r.value == q.value
+    capi.check(lib.ststhip_memcpy_d2h(C.c_void_p(host.data_ptr()), r, n, None), "d2h")
+    capi.check(lib.ststhip_stream_synchronize(None), "sync")
+    assert int(host.min()) == 3 and int(host.max()) == 3
+    capi.check(lib.ststhip_free(r), "free")
+    capi.check(lib.ststhip_stream_destroy(s1), "stream")
+    capi.check(lib.ststhip_stream_destroy(s2), "stream")
