@@ -139,3 +139,51 @@ def test_strips_of_several_processes_on_one_gpu(gpu, oracle, tmp_path, world):
         want = oracle.jacobi("Jacobi5General", coef, grid, 37, halo=halo, n_threads=8)
         got = np.concatenate([np.load(tmp_path / f"{tag}{r}.npy") for r in range(world)], axis=0)
         assert np.array_equal(bits(got), bits(want)), tag
+
+
+def _rccl_rank(rank, world, id_file, result_dir):
+    """One process per GPU, ghost rows over RCCL: the configuration bench.py --gpus N runs."""
+    import sys
+    import time
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from stencilstream_amd import capi
+
+    torch.cuda.set_device(rank)
+    capi.init(rank)
+    if rank == 0:
+        with open(id_file + ".tmp", "wb") as f:
+            f.write(capi.comm_unique_id())
+        os.replace(id_file + ".tmp", id_file)
+    while not os.path.exists(id_file):
+        time.sleep(0.05)
+    comm = capi.comm_create(open(id_file, "rb").read(), rank, world)
+    H, W = 4000, 3000
+    grid = np.random.default_rng(5).random((H, W), dtype=np.float32)
+    p = capi.JacobiParams()
+    for i in range(5):
+        p.coef[i] = 0.2
+    strip = capi.Strip("jacobi5general", p, np.float32(0.0).tobytes(), H, W, rank, world, comm=comm)
+    strip.upload(0, grid[strip.row_begin:strip.row_end])
+    strip.warm_up()
+    strip.advance(0, 40)
+    strip.advance(40, 9, blocking=True)
+    np.save(os.path.join(result_dir, f"rccl{rank}.npy"), strip.download(0, np.float32))
+    strip.close()
+
+
+def test_strips_over_rccl_on_several_gpus(gpu, oracle, tmp_path):
+    """Needs at least two GPUs in the box (the pool's test boxes have one: skipped there)."""
+    import torch
+    import torch.multiprocessing as mp
+
+    world = min(torch.cuda.device_count(), 4)
+    if world < 2:
+        pytest.skip("one GPU visible: RCCL cannot join two ranks on one device")
+    mp.spawn(_rccl_rank, args=(world, str(tmp_path / "rccl.id"), str(tmp_path)), nprocs=world, join=True)
+    grid = np.random.default_rng(5).random((4000, 3000), dtype=np.float32)
+    want = oracle.jacobi("Jacobi5General", [0.2] * 5, grid, 49, halo=0.0, n_threads=8)
+    got = np.concatenate([np.load(tmp_path / f"rccl{r}.npy") for r in range(world)], axis=0)
+    assert np.array_equal(bits(got), bits(want))
