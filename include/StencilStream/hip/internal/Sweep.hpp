@@ -874,7 +874,9 @@ inline int pick_chunk_rows(int out_rows, unsigned n_strips, int halo_rows, int r
     // weight shrinks by their number (fitted to chunk sweeps of Jacobi 16384^2 and HotSpot 8192^2)
     const int side_by_side = std::max(1, ststhip_launch_concurrency());
     const double slots = double(cus) * std::max(resident_blocks, 1) * waves_per_block;
-    const double alpha = env_int("STSTHIP_TAIL_PERMILLE", 500) / 1000.0 / side_by_side;
+    // tail weight: 0.5 for a launch that has the chip to itself; launches that run side by side (their boundary
+    // bands on streams of their own) want slightly longer chunks still (profiles/r02_ab_bands_beside.txt)
+    const double alpha = env_int("STSTHIP_TAIL_PERMILLE", side_by_side > 1 ? 350 : 500) / 1000.0 / side_by_side;
     const double overhead = 2.0 * halo_rows + 8.0;
     double rows = std::sqrt(double(out_rows) * double(n_strips) * overhead / (alpha * slots));
     rows = std::max(rows, 1.0);

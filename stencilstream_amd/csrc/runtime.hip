@@ -90,6 +90,31 @@ static bool side_streams_for(hipStream_t caller, int n, std::vector<hipStream_t>
     out.assign(pool.begin(), pool.begin() + n);
     return true;
 }
+// Streams for the boundary bands of row strips: highest priority, so that a band's few waves get the wave slots
+// that free up first instead of queueing behind the pending workgroups of an interior launch.
+static std::map<hipStream_t, std::vector<hipStream_t>> &band_streams() {
+    static std::map<hipStream_t, std::vector<hipStream_t>> streams;
+    return streams;
+}
+static hipError_t create_band_stream(hipStream_t *stream) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
+        greatest = 0;
+    return hipStreamCreateWithPriority(stream, hipStreamNonBlocking, greatest);
+}
+static bool band_streams_for(hipStream_t caller, int n, std::vector<hipStream_t> &out) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> guard(r.lock);
+    auto &pool = band_streams()[caller];
+    while (int(pool.size()) < n) {
+        hipStream_t extra;
+        if (create_band_stream(&extra) != hipSuccess)
+            return false;
+        pool.push_back(extra);
+    }
+    out.assign(pool.begin(), pool.begin() + n);
+    return true;
+}
 
 static std::vector<AppEntry> &apps() {
     static std::vector<AppEntry> registry;
@@ -384,6 +409,12 @@ int ststhip_shutdown(void) {
             (void)hipStreamDestroy(extra);
         }
     side_streams().clear();
+    for (auto &per_caller : band_streams())
+        for (hipStream_t extra : per_caller.second) {
+            (void)hipStreamSynchronize(extra);
+            (void)hipStreamDestroy(extra);
+        }
+    band_streams().clear();
     release_free_blocks(r);
     for (auto &kv : r.free_host_blocks)
         (void)hipHostFree(kv.second);
@@ -1014,9 +1045,31 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         std::vector<std::uint64_t> bound(strips + 1);
         for (int v = 0; v <= strips; v++)
             bound[v] = H * std::uint64_t(v) / std::uint64_t(strips);
-        if (strips == 2) // unequal strips drift out of phase, so one strip's tail meets the other's bulk
-            bound[1] = H * std::uint64_t(stencil::hip::internal::env_int("STSTHIP_STRIP_SKEW_PERMILLE", 400)) / 1000;
-        std::vector<hipEvent_t> bands_done(strips, nullptr); // per strip: bands of the previous pass
+        // unequal strips drift out of phase, so one strip's tail meets the other's bulk (400 while the bands sat in
+        // front of the interiors); with the bands beside the interiors equal strips are as good or better
+        if (strips == 2)
+            bound[1] = H * std::uint64_t(stencil::hip::internal::env_int(
+                               "STSTHIP_STRIP_SKEW_PERMILLE",
+                               stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1) ? 500 : 400)) / 1000;
+        // Boundary bands on streams of their own (highest priority), beside the interior of the same strip and
+        // pass: a band's output only feeds the NEXT pass, and in the strip's own stream it sat in front of the
+        // interior for 110-165 us per pass (12 rows of work that queue behind the other strip's resident waves;
+        // profiles/r02_bench_summary.json, launch shape 12544).  Dependencies per pass p and strip v:
+        //   bands(v, p)    after interior(v, p-1), bands(v-1, p-1), bands(v+1, p-1)   [own bands(p-1): stream order]
+        //   interior(v, p) after bands(v-1 .. v+1, p-1)                               [own interior(p-1): stream order]
+        // -- every row a launch reads was written by one of those, and every row it overwrites (the other buffer
+        // set) was last read by one of those.
+        std::vector<hipStream_t> band_lane(strips, nullptr);
+        const bool bands_beside = strips > 1 && stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1) != 0 &&
+                                  band_streams_for(s, strips, band_lane);
+        if (bands_beside) {
+            hipEvent_t begin = new_event();
+            ordered(hipEventRecord(begin, s), "hipEventRecord");
+            for (int v = 0; v < strips; v++)
+                ordered(hipStreamWaitEvent(band_lane[v], begin, 0), "hipStreamWaitEvent");
+        }
+        std::vector<hipEvent_t> bands_done(strips, nullptr);    // per strip: bands of the previous pass
+        std::vector<hipEvent_t> interior_done(strips, nullptr); // per strip: interior of the previous pass
         g_launch_concurrency = strips;
 
         // the last pass must land in dst; the input is never written
@@ -1035,7 +1088,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                 ordered(hipEventCreate(&t1), "hipEventCreate");
                 ordered(hipEventRecord(t0, s), "hipEventRecord");
             }
-            std::vector<hipEvent_t> bands_now(strips, nullptr);
+            std::vector<hipEvent_t> bands_now(strips, nullptr), interior_now(strips, nullptr);
             for (int v = 0; v < strips && rc == STSTHIP_OK; v++) {
                 const std::uint64_t a = bound[v], b = bound[v + 1];
                 if (strips == 1) {
@@ -1043,30 +1096,45 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                     n_launches++;
                     continue;
                 }
+                hipStream_t bands_on = bands_beside ? band_lane[v] : lane[v];
                 // bands read the neighbours' bands of the previous pass (and will overwrite rows
                 // the neighbours' previous bands read): wait for them
                 if (v > 0 && bands_done[v - 1])
-                    ordered(hipStreamWaitEvent(lane[v], bands_done[v - 1], 0), "hipStreamWaitEvent");
+                    ordered(hipStreamWaitEvent(bands_on, bands_done[v - 1], 0), "hipStreamWaitEvent");
                 if (v + 1 < strips && bands_done[v + 1])
-                    ordered(hipStreamWaitEvent(lane[v], bands_done[v + 1], 0), "hipStreamWaitEvent");
+                    ordered(hipStreamWaitEvent(bands_on, bands_done[v + 1], 0), "hipStreamWaitEvent");
+                if (bands_beside && interior_done[v])
+                    ordered(hipStreamWaitEvent(bands_on, interior_done[v], 0), "hipStreamWaitEvent");
                 const std::uint64_t top_end = (v > 0) ? std::min(a + g, b) : a;
                 const std::uint64_t bot_begin = (v + 1 < strips) ? std::max(b - std::min(g, b - a), top_end) : b;
                 if (top_end > a) {
-                    rc = sweep(ctx, dom, from, to, a, top_end, iteration, depths[pass], lane[v]);
+                    rc = sweep(ctx, dom, from, to, a, top_end, iteration, depths[pass], bands_on);
                     n_launches++;
                 }
                 if (rc == STSTHIP_OK && bot_begin < b) {
-                    rc = sweep(ctx, dom, from, to, bot_begin, b, iteration, depths[pass], lane[v]);
+                    rc = sweep(ctx, dom, from, to, bot_begin, b, iteration, depths[pass], bands_on);
                     n_launches++;
                 }
                 bands_now[v] = new_event();
-                ordered(hipEventRecord(bands_now[v], lane[v]), "hipEventRecord");
+                ordered(hipEventRecord(bands_now[v], bands_on), "hipEventRecord");
+                if (bands_beside) {
+                    // the interior reads this strip's previous bands, and -- when this pass is shallower than the
+                    // previous one -- overwrites rows next to them that the neighbours' previous bands read
+                    for (int w = std::max(v - 1, 0); w <= std::min(v + 1, strips - 1); w++)
+                        if (bands_done[w])
+                            ordered(hipStreamWaitEvent(lane[v], bands_done[w], 0), "hipStreamWaitEvent");
+                }
                 if (rc == STSTHIP_OK && top_end < bot_begin) {
                     rc = sweep(ctx, dom, from, to, top_end, bot_begin, iteration, depths[pass], lane[v]);
                     n_launches++;
                 }
+                if (bands_beside) {
+                    interior_now[v] = new_event();
+                    ordered(hipEventRecord(interior_now[v], lane[v]), "hipEventRecord");
+                }
             }
             bands_done.swap(bands_now);
+            interior_done.swap(interior_now);
             if (profiling) {
                 ordered(hipEventRecord(t1, s), "hipEventRecord");
                 timed.emplace_back(t0, t1);
@@ -1074,6 +1142,13 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             from = const_cast<const void *const *>(to);
             iteration += depths[pass];
         }
+        // the band streams join the caller's stream too
+        if (bands_beside)
+            for (int v = 0; v < strips; v++) {
+                hipEvent_t done = new_event();
+                ordered(hipEventRecord(done, band_lane[v]), "hipEventRecord");
+                ordered(hipStreamWaitEvent(s, done, 0), "hipStreamWaitEvent");
+            }
         g_launch_concurrency = 1;
         g_target_holds_constants = 0;
         g_tdv_table = nullptr;
@@ -1380,7 +1455,7 @@ struct Strip {
     void *planes[2][16] = {{nullptr}};
     int current = 0;
     hipStream_t compute = nullptr, comm_stream = nullptr;
-    std::vector<hipStream_t> side;
+    std::vector<hipStream_t> side, band; // interiors of further sub-strips; boundary bands (highest priority)
     ststhip_domain dom;        // geometry of the buffers (in words for the packed Game of Life)
     std::uint64_t n_launches = 0, n_exchanges = 0;
 };
@@ -1508,6 +1583,10 @@ int ststhip_strip_destroy(ststhip_strip strip) {
         (void)hipStreamSynchronize(lane);
         (void)hipStreamDestroy(lane);
     }
+    for (hipStream_t lane : st->band) {
+        (void)hipStreamSynchronize(lane);
+        (void)hipStreamDestroy(lane);
+    }
     for (auto &set : st->planes)
         for (void *plane : set)
             if (plane)
@@ -1626,8 +1705,8 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     std::vector<std::uint64_t> bound(n_sub + 1);
     for (int v = 0; v <= n_sub; v++)
         bound[v] = a + (b - a) * std::uint64_t(v) / std::uint64_t(n_sub);
-    if (n_sub == 2) // unequal strips drift out of phase, so one strip's tail meets the other's bulk
-        bound[1] = a + (b - a) * 2 / 5;
+    if (n_sub == 2 && !stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1))
+        bound[1] = a + (b - a) * 2 / 5; // bands in front of the interiors: unequal strips drift out of phase
     while (int(st->side.size()) < n_sub - 1) {
         hipStream_t lane;
         if (hipStreamCreateWithFlags(&lane, hipStreamNonBlocking) != hipSuccess)
@@ -1637,49 +1716,75 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     std::vector<hipStream_t> lanes(n_sub, st->compute);
     for (int v = 1; v < n_sub; v++)
         lanes[v] = st->side[v - 1];
-    const bool has_up = st->rank > 0, has_down = st->rank + 1 < st->n_ranks;
+    // boundary bands on highest-priority streams of their own, beside the interior of the same sub-strip and pass
+    // (the dependency rule of ststhip_run_passes; bands at the strip's ends additionally wait for the ghost rows)
+    const bool bands_beside = stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1) != 0;
+    while (bands_beside && int(st->band.size()) < n_sub) {
+        hipStream_t lane;
+        if (create_band_stream(&lane) != hipSuccess)
+            return hip_fail(hipErrorUnknown, "hipStreamCreateWithPriority");
+        st->band.push_back(lane);
+    }
+    // STSTHIP_STRIP_DEBUG_BANDS=1 (timing experiments on one GPU only, results are WRONG at the strip's ends): launch
+    // the bands a strip with neighbours on both sides launches, without the exchange
+    const bool pretend = stencil::hip::internal::env_int("STSTHIP_STRIP_DEBUG_BANDS", 0) != 0;
+    const bool has_up = st->rank > 0 || pretend, has_down = st->rank + 1 < st->n_ranks || pretend;
     g_launch_concurrency = n_sub;
 
     hipEvent_t begin = record(st->compute); // everything queued so far: a previous advance, uploads
     wait(st->comm_stream, begin);
     for (int v = 1; v < n_sub; v++)
         wait(lanes[v], begin);
+    if (bands_beside)
+        for (int v = 0; v < n_sub; v++)
+            wait(st->band[v], begin);
     hipEvent_t ghosts_ready = nullptr;
     if (st->n_ranks > 1 && rc == STSTHIP_OK) {
         rc = strip_exchange(*st, st->current, depths[0] * hpg);
         ghosts_ready = record(st->comm_stream);
     }
-    std::vector<hipEvent_t> bands_done(n_sub, nullptr);
+    std::vector<hipEvent_t> bands_done(n_sub, nullptr), interior_done(n_sub, nullptr);
     std::uint64_t iteration = iteration_offset;
     for (std::size_t i = 0; i < depths.size() && rc == STSTHIP_OK; i++) {
         const std::uint32_t depth = depths[i];
         const std::uint64_t g = depth * hpg;
         const void *const *src = const_cast<const void *const *>(st->planes[st->current]);
         void *const *dst = st->planes[st->current ^ 1];
-        std::vector<hipEvent_t> bands_now(n_sub, nullptr);
+        std::vector<hipEvent_t> bands_now(n_sub, nullptr), interior_now(n_sub, nullptr);
         for (int v = 0; v < n_sub && rc == STSTHIP_OK; v++) {
             const std::uint64_t va = bound[v], vb = bound[v + 1];
             hipStream_t lane = lanes[v];
+            hipStream_t bands_on = bands_beside ? st->band[v] : lane;
             const bool up = v > 0 || has_up;            // somebody above needs (and feeds) my top rows
             const bool down = v + 1 < n_sub || has_down;
             if (v > 0)
-                wait(lane, bands_done[v - 1]);
+                wait(bands_on, bands_done[v - 1]);
             if (v + 1 < n_sub)
-                wait(lane, bands_done[v + 1]);
+                wait(bands_on, bands_done[v + 1]);
             if ((v == 0 && has_up) || (v == n_sub - 1 && has_down))
-                wait(lane, ghosts_ready);
+                wait(bands_on, ghosts_ready);
+            if (bands_beside)
+                wait(bands_on, interior_done[v]);
             const std::uint64_t top_end = up ? std::min(va + g, vb) : va;
             const std::uint64_t bot_begin = down ? std::max(vb - std::min(g, vb - va), top_end) : vb;
-            auto sweep = [&](std::uint64_t r0, std::uint64_t r1) {
+            auto sweep = [&](std::uint64_t r0, std::uint64_t r1, hipStream_t on) {
                 if (r0 < r1 && rc == STSTHIP_OK) {
-                    rc = st->resolved.trampoline(st->resolved.ctx, &st->dom, src, dst, r0, r1, iteration, depth, lane);
+                    rc = st->resolved.trampoline(st->resolved.ctx, &st->dom, src, dst, r0, r1, iteration, depth, on);
                     st->n_launches++;
                 }
             };
-            sweep(va, top_end);
-            sweep(bot_begin, vb);
-            bands_now[v] = record(lane);
-            sweep(top_end, bot_begin);
+            sweep(va, top_end, bands_on);
+            sweep(bot_begin, vb, bands_on);
+            bands_now[v] = record(bands_on);
+            if (bands_beside) {
+                // the interior reads the rows of this sub-strip's previous bands and, when this pass is shallower
+                // than the previous one, overwrites rows next to them that the neighbours' previous bands read
+                for (int w = std::max(v - 1, 0); w <= std::min(v + 1, n_sub - 1); w++)
+                    wait(lane, bands_done[w]);
+            }
+            sweep(top_end, bot_begin, lane);
+            if (bands_beside)
+                interior_now[v] = record(lane);
         }
         if (i + 1 < depths.size() && st->n_ranks > 1 && rc == STSTHIP_OK) {
             wait(st->comm_stream, bands_now[0]);
@@ -1688,6 +1793,7 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
             ghosts_ready = record(st->comm_stream);
         }
         bands_done.swap(bands_now);
+        interior_done.swap(interior_now);
         st->current ^= 1;
         iteration += depth;
     }
@@ -1695,6 +1801,9 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     // the compute stream is the one callers synchronise with
     for (int v = 1; v < n_sub; v++)
         wait(st->compute, record(lanes[v]));
+    if (bands_beside)
+        for (int v = 0; v < n_sub; v++)
+            wait(st->compute, record(st->band[v]));
     wait(st->compute, record(st->comm_stream));
     if (rc == STSTHIP_OK && blocking) {
         hipError_t err = hipStreamSynchronize(st->compute);
