@@ -1549,8 +1549,10 @@ int ststhip_strip_create(const char *app, const void *tf_params, const void *hal
     st->dom.row_origin = st->row_origin;
     st->dom.local_rows = st->local_rows;
     hipError_t err = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
+    // the exchange stream has the highest priority as well: the send / receive kernels of RCCL are a workgroup or
+    // two and would otherwise queue for wave slots behind the interiors they are meant to overlap with
     if (err == hipSuccess)
-        err = hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking);
+        err = create_band_stream(&st->comm_stream);
     for (int set = 0; set < 2 && err == hipSuccess && rc == STSTHIP_OK; set++)
         for (unsigned p = 0; p < st->n_planes && rc == STSTHIP_OK; p++) {
             st->elem[p] = e->info.plane_elem_size[p];

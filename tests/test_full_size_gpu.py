@@ -10,8 +10,6 @@ two row strips of the pass driver, and -- FDTD -- on the source cell.
 
 Both layouts (per-field planes and AoS) go through ststhip_app_run with >= 3 launches per run, so the planes
 kernels that leave out the stores of constant fields (hotspot `power`, FDTD `ca..db`) are the ones checked."""
-import os
-
 import numpy as np
 import pytest
 
