@@ -398,11 +398,31 @@ struct SweepGeometry {
     std::uint64_t iteration;            // generation index of the first level
     std::uint32_t xcd_remap;            // 1: give every XCD a contiguous range of the wave grid
     std::uint32_t last_chunk_early;     // 1: the last row chunk is dispatched second instead of last
+    // Persistent waves (sweep_kernel<..., PERSISTENT>): the rows are cut into fine chunks of `fine_rows`; a wave
+    // claims a chunk, and when it has finished it claims the chunk BELOW and keeps streaming -- its pipeline holds
+    // exactly the state that chunk needs, so only the first chunk of a run pays the 2G warm-up rows -- until it
+    // meets a chunk somebody else has claimed; then it takes the next unclaimed chunk from a shared cursor.
+    std::uint32_t fine_rows, n_fine;    // rows per fine chunk, chunks per strip
+    std::uint32_t starts_per_strip;     // runs that start side by side in one strip (cursor phase 0)
+    std::uint32_t start_stride;         // distance of those starts in chunks
+    std::uint32_t phase_step;           // chunks between the starts of consecutive ticket phases
+    std::uint32_t cursor_end;           // tickets: phases * starts_per_strip * n_strips
+    std::uint32_t *claims;              // one word per (chunk, strip), zeroed before the launch
+    std::uint32_t *cursor;              // one word, zeroed before the launch
 };
 
 template <typename F, bool SOA> constexpr bool cooperative_for() {
     if constexpr (requires { SweepTuning<F, SOA>::cooperative; })
         return SweepTuning<F, SOA>::cooperative;
+    else
+        return false;
+}
+
+// SweepTuning<F, SOA>::persistent (optional member, default false): launch as many waves as stay resident and let
+// each claim fine row chunks, continuing into the chunk below without re-warming its pipeline (SweepGeometry).
+template <typename F, bool SOA> constexpr bool persistent_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::persistent; })
+        return SweepTuning<F, SOA>::persistent;
     else
         return false;
 }
@@ -481,6 +501,7 @@ struct Sweep {
     static constexpr int OW_PER_WAVE = COOP ? OW / waves_per_block : OW; // what the launch heuristics count waves with
     static constexpr int NWIN = 2 * R;          // rows each level keeps
     static constexpr int D = 2 * R + 1;
+    static constexpr int prefetch_depth = P;
 
     // COOP: edge columns in LDS.  Slot (step mod N_SLOTS) holds, per level and wave, the R westernmost cells of
     // lane 0 and the R easternmost cells of lane 63 of the row that entered that level's window in that step.
@@ -514,15 +535,22 @@ struct Sweep {
     // SKIP_CONSTANTS: the target planes of F::constant_fields already hold their values (see
     // constant_plane_mask); their stores are left out
     // `strip`: index of the unit (wave, or workgroup if COOP) along the columns; `wib`: wave in the workgroup
-    template <bool EDGE, bool SKIP_CONSTANTS>
-    STST_DEVICE static void run(Args const &a, const int lane, const int strip, const int ya,
-                                const int yb, const int wib, std::uint32_t *lds) {
+    // `more_rows(yb)`: persistent waves only -- called when the rows up to yb are done, returns the new end of the
+    // wave's rows if it could claim the chunk below (then the wave keeps streaming), or yb.
+    // Returns the row the wave's output ends at.
+    template <bool EDGE, bool SKIP_CONSTANTS, typename MoreRows>
+    STST_DEVICE static int run(Args const &a, const int lane, const int strip, const int ya,
+                               const int yb_first, const int wib, std::uint32_t *lds, MoreRows more_rows) {
+        constexpr bool CONTINUES = !std::is_same_v<MoreRows, std::nullptr_t>;
+        int yb = yb_first;
         constexpr std::uint32_t skip_mask = SKIP_CONSTANTS ? constant_plane_mask<F>() : 0u;
         SweepGeometry const &g = a.geo;
         const int unit_x = COOP ? wib * LW + lane * K : lane * K; // column of the lane inside its unit
         const int x0 = strip * OW - GX + unit_x; // global column of the lane's first cell
         const int ystart = ya - G;
-        const int y_load_end = yb + G < g.load_hi ? yb + G : g.load_hi;
+        // a wave that may continue below its chunk prefetches real rows there: up to what the launch may read
+        const int y_load_end = CONTINUES ? (g.out_end + G < g.load_hi ? g.out_end + G : g.load_hi)
+                                         : (yb + G < g.load_hi ? yb + G : g.load_hi);
 
         bool col_in[K];
 #pragma unroll
@@ -603,7 +631,7 @@ struct Sweep {
         // wave) level l only has to produce rows from input row 2*l*R of the wave on -- earlier outputs
         // cannot reach a stored row -- so the deeper levels are skipped by wave-uniform branches: a
         // trapezoid of level-steps instead of a parallelogram, G*(S+1) fewer of them per wave.
-        const int n_rows_in = yb - ya + 2 * G;
+        int n_rows_in = yb - ya + 2 * G;
         auto row_step = [&](auto u, const int it, auto filling) __attribute__((always_inline)) {
                 constexpr bool FILLING = decltype(filling)::value;
                 const int step = it + u; // index of the input row inside the wave
@@ -788,6 +816,20 @@ struct Sweep {
         }
         for (; it < n_rows_in; it += P)
             static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, it, std::false_type{}); });
+        if constexpr (CONTINUES) {
+            // exactly n_rows_in rows have been fed (the launcher keeps chunk lengths and 2G multiples of P): the
+            // pipeline is in the state the chunk below starts from
+            while (it == n_rows_in) {
+                const int further = more_rows(yb);
+                if (further == yb)
+                    break;
+                yb = further;
+                n_rows_in = yb - ya + 2 * G;
+                for (; it < n_rows_in; it += P)
+                    static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, it, std::false_type{}); });
+            }
+        }
+        return yb;
     }
 
     template <bool SKIP_CONSTANTS = false> STST_DEVICE static void entry(Args const &a, std::uint32_t *lds) {
@@ -829,11 +871,78 @@ struct Sweep {
             const bool interior =
                 xw0 >= 0 && xw0 + UW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
             if (interior)
-                run<false, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds);
+                run<false, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, nullptr);
             else
-                run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds);
+                run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, nullptr);
         } else {
-            run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds);
+            run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, nullptr);
+        }
+    }
+
+    // ---- persistent waves (see SweepGeometry) ----
+    static constexpr bool can_continue = !COOP && (2 * G) % P == 0;
+
+    STST_DEVICE static bool claim(SweepGeometry const &g, std::uint32_t item, int lane) {
+        std::uint32_t got = 0;
+        if (lane == 0)
+            got = atomicCAS(g.claims + item, 0u, 1u) == 0u ? 1u : 0u;
+        return __builtin_amdgcn_readfirstlane(got) != 0;
+    }
+    STST_DEVICE static bool chunk_is_interior(SweepGeometry const &g, int strip, int ya, int yb) {
+        const int xw0 = strip * OW - GX;
+        return INTERIOR_VARIANT && xw0 >= 0 && xw0 + UW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
+    }
+
+    template <bool SKIP_CONSTANTS = false> STST_DEVICE static void entry_persistent(Args const &a, std::uint32_t *lds) {
+        SweepGeometry const &g = a.geo;
+        const int lane = int(threadIdx.x) & (wave_size - 1);
+        const int wib = int(__builtin_amdgcn_readfirstlane(threadIdx.x / wave_size));
+        // One ticket per wave, in dispatch order.  The first starts_per_strip * n_strips tickets (one residency
+        // round) start runs evenly spaced in every strip; a run goes down its strip chunk by chunk until the chunk
+        // below belongs to somebody else -- who by the same rule takes care of everything below it -- so every chunk
+        // is swept exactly once.  The later tickets (phases 1, 2, ...) point at chunks inside those runs' ranges:
+        // their waves only start when a slot frees up, find their chunk taken if the run above has got there (then
+        // they end at once), and otherwise split what a slow or late run has left.  No wave waits for another.
+        const std::uint32_t ticket = __builtin_amdgcn_readfirstlane(blockIdx.x * std::uint32_t(waves_per_block) + std::uint32_t(wib));
+        if (ticket >= g.cursor_end)
+            return;
+        const std::uint32_t per_phase = g.starts_per_strip * g.n_strips;
+        const std::uint32_t phase = ticket / per_phase, rest = ticket % per_phase;
+        const int strip = int(rest % g.n_strips);
+        std::uint32_t chunk = (rest / g.n_strips) * g.start_stride + phase * g.phase_step;
+        if (chunk >= g.n_fine || !claim(g, chunk * g.n_strips + std::uint32_t(strip), lane))
+            return;
+        for (;;) {
+            const int ya = g.out_begin + int(chunk * g.fine_rows);
+            int yb = ya + int(g.fine_rows);
+            yb = yb < g.out_end ? yb : g.out_end;
+            const bool interior = chunk_is_interior(g, strip, ya, yb);
+            // the chunk below, if it is free and runs the same code path (interior / edge): keep streaming
+            auto more_rows = [&](int done_to) __attribute__((always_inline)) -> int {
+                if (done_to >= g.out_end)
+                    return done_to;
+                const std::uint32_t next = std::uint32_t(done_to - g.out_begin) / g.fine_rows;
+                int next_end = done_to + int(g.fine_rows);
+                next_end = next_end < g.out_end ? next_end : g.out_end;
+                if (chunk_is_interior(g, strip, done_to, next_end) != interior)
+                    return done_to;
+                return claim(g, next * g.n_strips + std::uint32_t(strip), lane) ? next_end : done_to;
+            };
+            int done_to;
+            if constexpr (INTERIOR_VARIANT) {
+                if (interior)
+                    done_to = run<false, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, more_rows);
+                else
+                    done_to = run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, more_rows);
+            } else {
+                done_to = run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, more_rows);
+            }
+            // the code path changes at the chunk below (or the feed did not end on a chunk boundary): a fresh run
+            if (done_to >= g.out_end)
+                return;
+            chunk = std::uint32_t(done_to - g.out_begin) / g.fine_rows;
+            if (!claim(g, chunk * g.n_strips + std::uint32_t(strip), lane))
+                return;
         }
     }
 };
@@ -845,10 +954,13 @@ using SweepOf = Sweep<F, SOA, T, SweepTuning<F, SOA>::cells_per_lane, SweepTunin
                       INLINE_TDV>;
 
 // MIN_WAVES = waves per SIMD the register allocator must leave room for (launch-bounds semantics).
-template <typename SW, int MIN_WAVES = 1, bool SKIP_CONSTANTS = false>
+template <typename SW, int MIN_WAVES = 1, bool SKIP_CONSTANTS = false, bool PERSISTENT = false>
 __global__ void __launch_bounds__(256, MIN_WAVES) sweep_kernel(const typename SW::Args args) {
     __shared__ std::uint32_t edge_columns[SW::LDS_WORDS]; // cooperative strips only (one word otherwise)
-    SW::template entry<SKIP_CONSTANTS>(args, edge_columns);
+    if constexpr (PERSISTENT)
+        SW::template entry_persistent<SKIP_CONSTANTS>(args, edge_columns);
+    else
+        SW::template entry<SKIP_CONSTANTS>(args, edge_columns);
 }
 
 // ------------------------------------------------------------------ host side
@@ -939,6 +1051,8 @@ inline void plan_tiers(SweepGeometry &g, int out_rows) {
     g.tier_first[g.n_tiers] = g.n_chunks;
 }
 
+template <typename SW> constexpr int P_rows() { return SW::prefetch_depth; }
+
 // One kernel launch = T generations over global rows [out_begin, out_end).  `tdv`: the T time-dependent values
 // evaluated on the host, or nullptr when the kernel takes them from the pass driver's device table
 // (ststhip_current_tdv_table) or evaluates them itself (INLINE_TDV).
@@ -1010,17 +1124,59 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         else if (!tdv)
             throw std::invalid_argument("no time-dependent values for this launch");
     }
+    // persistent waves: one residency round of waves that claim fine row chunks and continue downwards
+    void *claim_words = nullptr;
+    bool persistent = false;
+    g.fine_rows = g.n_fine = g.starts_per_strip = g.start_stride = g.phase_step = g.cursor_end = 0;
+    g.claims = g.cursor = nullptr;
+    if constexpr (persistent_for<F, SOA>() && SW::can_continue) {
+        const int rows = int(out_end - out_begin);
+        int fine = env_int("STSTHIP_FINE_ROWS", 32);
+        fine = round_up(std::max(fine, P_rows<SW>()), P_rows<SW>());
+        if (env_int("STSTHIP_PERSISTENT", 1) && rows >= 8 * fine) {
+            int cus = 256;
+            ststhip_compute_units(&cus);
+            std::uint32_t slots = std::uint32_t(cus) * std::uint32_t(std::max(resident_blocks, 1)) * waves_per_block /
+                                  std::uint32_t(std::max(1, ststhip_launch_concurrency()));
+            slots = std::uint32_t(std::uint64_t(slots) * std::uint64_t(env_int("STSTHIP_PERSISTENT_FILL_PERMILLE", 1000)) / 1000);
+            g.fine_rows = std::uint32_t(fine);
+            g.n_fine = std::uint32_t((rows + fine - 1) / fine);
+            g.starts_per_strip = std::min(std::max(slots / g.n_strips, 1u), g.n_fine);
+            g.start_stride = (g.n_fine + g.starts_per_strip - 1) / g.starts_per_strip;
+            g.phase_step = std::max(1u, g.start_stride / std::uint32_t(std::max(1, env_int("STSTHIP_PERSISTENT_PHASES", 4))));
+            g.cursor_end = ((g.start_stride + g.phase_step - 1) / g.phase_step) * g.starts_per_strip * g.n_strips;
+            const std::size_t n_words = std::size_t(g.n_fine) * g.n_strips;
+            check(ststhip_malloc_async(&claim_words, n_words * 4, stream), "claim table");
+            check(ststhip_memset(claim_words, 0, n_words * 4, stream), "claim table");
+            g.claims = static_cast<std::uint32_t *>(claim_words);
+            g.cursor = nullptr;
+            kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, false, true>);
+            if constexpr (SOA && constant_plane_mask<F>() != 0)
+                if (ststhip_target_holds_constants() && env_int("STSTHIP_SKIP_CONSTANT_STORES", 1))
+                    kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, true, true>);
+            persistent = true;
+        }
+    }
     // transition functions need not be default-constructible: build the argument block in one go
     typename SW::Args args = [&]<std::size_t... Is>(std::index_sequence<Is...>) {
         return typename SW::Args{f, halo, {((table || !tdv) ? TDV{} : tdv[Is])...}, table, src, dst, g};
     }(std::make_index_sequence<std::size_t(T)>{});
 
     const unsigned units = g.n_strips * g.n_chunks;
-    const unsigned blocks = coop ? units : (units + waves_per_block - 1) / waves_per_block;
+    unsigned blocks = coop ? units : (units + waves_per_block - 1) / waves_per_block;
+    if (persistent) {
+        int cus = 256;
+        ststhip_compute_units(&cus);
+        const unsigned resident = unsigned(cus) * unsigned(std::max(resident_blocks, 1)) /
+                                  unsigned(std::max(1, ststhip_launch_concurrency()));
+        (void)resident;
+        blocks = std::max(1u, (g.cursor_end + waves_per_block - 1) / waves_per_block); // one wave per ticket
+    }
     void *kernel_args[] = {&args};
-    check(ststhip_launch(kernel, blocks, 1, 1,
-                         waves_per_block * wave_size, 1, 1, kernel_args, 0, stream),
-          "sweep launch");
+    const int launched = ststhip_launch(kernel, blocks, 1, 1, waves_per_block * wave_size, 1, 1, kernel_args, 0, stream);
+    if (claim_words)
+        ststhip_free_async(claim_words, stream); // released behind the launch
+    check(launched, "sweep launch");
 }
 
 // Runtime n_generations -> compiled T (powers of two up to the tuning's maximum).

@@ -106,7 +106,9 @@ template <typename F, bool SOA> struct AppAdapter {
 
 // A transition function with an explicit pipeline shape (used to register tuning experiments and
 // hand-picked shapes next to the heuristic default).
-template <typename F, int K, int T, int P, int MINW = 1, bool INTERIOR = true, bool COOP = false, int DBG = 0> struct Shaped : public F {
+template <typename F, int K, int T, int P, int MINW = 1, bool INTERIOR = true, bool COOP = false, int DBG = 0,
+          bool PERSIST = false>
+struct Shaped : public F {
     using Block = typename F::Block;
     Shaped() = default;
     Shaped(F const &f) : F(f) {}
@@ -121,9 +123,10 @@ struct AppRegistrar {
 
 namespace stencil {
 namespace hip {
-template <typename F, int K, int T, int P, int MINW, bool INTERIOR, bool COOP, int DBG, bool SOA>
-struct SweepTuning<::ststhip_detail::Shaped<F, K, T, P, MINW, INTERIOR, COOP, DBG>, SOA> {
+template <typename F, int K, int T, int P, int MINW, bool INTERIOR, bool COOP, int DBG, bool PERSIST, bool SOA>
+struct SweepTuning<::ststhip_detail::Shaped<F, K, T, P, MINW, INTERIOR, COOP, DBG, PERSIST>, SOA> {
     static constexpr int cooperative_debug = DBG;
+    static constexpr bool persistent = PERSIST;
     static constexpr int cells_per_lane = K;
     static constexpr int max_generations = T;
     static constexpr int prefetch_rows = P;

@@ -988,3 +988,55 @@ def test_pool_hands_blocks_over_in_stream_order(gpu):
     capi.check(lib.ststhip_free(r), "free")
     capi.check(lib.ststhip_stream_destroy(s1), "stream")
     capi.check(lib.ststhip_stream_destroy(s2), "stream")
+
+
+@pytest.mark.parametrize("shape", [(300, 257), (1200, 700), (4000, 1500)], ids=str)
+def test_persistent_waves_bit_exact(gpu, oracle, shape):
+    """sweep_kernel<..., PERSISTENT>: waves claim 32-row chunks and continue into the chunk below without re-warming
+    their pipeline ("jacobi5general_persistent"; launches of fewer than 256 rows use the chunked kernel): grids with a
+    few and with many chunks per strip, the launch depths 8 + 4 + 1 and 8 + 8 + 8 + 2, edge and interior code paths."""
+    from stencilstream_amd import capi, update as U
+
+    rng = np.random.default_rng(shape[0] + shape[1])
+    grid = rng.random(shape, dtype=np.float32)
+    coef = [0.1, 0.2, 0.3, 0.25, 0.15]
+    tf = U.TransitionFunction("jacobi5general_persistent", U.jacobi("Jacobi5General", coef).params, np.dtype("<f4"))
+    for n in (13, 26):
+        got = run_hip(tf, grid, n, halo=np.float32(0.125))
+        want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=0.125, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"n={n}"
+
+
+@pytest.mark.parametrize("strips", ["2", "3", "4"])
+def test_row_strips_with_bands_beside_interiors_full_size(gpu, monkeypatch, strips):
+    """The pass driver's row strips at BASELINE size with ragged launch depths (40 = 12 + 12 + 12 + 3 + 1 and
+    8 + 8 + 8 + 8 + 8): the boundary bands run on streams of their own beside the interiors, so the orderings between
+    them are events, not stream order -- a missing one (the interior of a shallower pass overwriting rows the
+    neighbour's previous band still reads) only shows on launches long enough to overlap.  Several repetitions
+    against the one-strip result, bit for bit."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    N = 16384
+    gen = torch.Generator(device="cuda").manual_seed(int(strips))
+    src = torch.rand(N, N, device=gpu, generator=gen)
+    dom = capi.Domain(N, N, 0, N, N)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for coef in ([0.2] * 5, [0.2, 0.21, 0.19, 0.22, 0.18]):
+        p = capi.JacobiParams()
+        for i, c in enumerate(coef):
+            p.coef[i] = c
+        monkeypatch.setenv("STSTHIP_VIRTUAL_STRIPS", "1")
+        want = torch.empty_like(src)
+        capi.app_run("jacobi5general", p, np.float32(0).tobytes(), dom, [src.data_ptr()], [want.data_ptr()], 0, 40,
+                     blocking=True, stream=s.cuda_stream)
+        monkeypatch.setenv("STSTHIP_VIRTUAL_STRIPS", strips)
+        got = torch.empty_like(src)
+        for _ in range(4):
+            got.zero_()
+            capi.app_run("jacobi5general", p, np.float32(0).tobytes(), dom, [src.data_ptr()], [got.data_ptr()], 0, 40,
+                         blocking=True, stream=s.cuda_stream)
+            assert torch.equal(got, want)
