@@ -305,7 +305,11 @@ def app_sweep(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, out_begin, ou
 
 def app_run(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, iteration_offset, n_iterations,
             blocking=True, profiling=False, stream=0):
-    """cuda::StencilUpdate::operator() for a precompiled transition function."""
+    """cuda::StencilUpdate::operator() for a precompiled transition function.
+
+    The work is queued on `stream` (0 = the library's own stream), which is NOT torch's current stream: tensors that
+    torch kernels have just filled or cleared must be complete first (torch.cuda.synchronize(), an event, or the
+    `on_stream` helper below), or the sweep races with them."""
     halo = C.create_string_buffer(bytes(halo_bytes), len(halo_bytes))
     src = _ptr_array(src_ptrs)
     dst = _ptr_array(dst_ptrs)

@@ -1037,6 +1037,7 @@ def test_row_strips_with_bands_beside_interiors_full_size(gpu, monkeypatch, stri
         got = torch.empty_like(src)
         for _ in range(4):
             got.zero_()
+            torch.cuda.synchronize()  # cleared on torch's stream, swept on `s`
             capi.app_run("jacobi5general", p, np.float32(0).tobytes(), dom, [src.data_ptr()], [got.data_ptr()], 0, 40,
                          blocking=True, stream=s.cuda_stream)
             assert torch.equal(got, want)
