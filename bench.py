@@ -51,8 +51,8 @@ COUNTER_FILE = os.path.join(ROOT, "profiles", "r02_bench_counters.json")
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=16384, help="rows and columns of the whole grid")
     ap.add_argument("--config5", action="store_true", help="BASELINE configs[4]: the 65536^2 grid")
     ap.add_argument("--rows-per-gpu", type=int, default=0,
