@@ -260,3 +260,13 @@ def test_reduce_max_abs_matches_numpy(gpu):
     assert got[2] == np.nanmax(np.abs(cells["c"][:, :10]))
     assert got[3] == -np.inf
     assert got[4] == np.nanmax(np.abs(cells["c"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,iterations", [(40, 7), (128, 100), (256, 100)])
+def test_convection_kernels_bit_identical_to_cpu_backend(res, iterations):
+    """The reference's PseudoTransientKernel (3 sub-iterations) and ThermalSolverKernel (2) on stencil::hip and on
+    stencil::cpu in one binary (examples/convection_bits_test.cpp): all 11 fp64 fields of every cell identical as
+    bits after two time steps."""
+    res = run([exe("convection_bits_test"), str(res), str(iterations)])
+    assert b"0 of" in res.stdout and b"differ" in res.stdout
