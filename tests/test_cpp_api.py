@@ -25,3 +25,17 @@ def test_hip_api():
     res = subprocess.run([binary], capture_output=True, timeout=600)
     assert res.returncode == 0, res.stdout.decode() + res.stderr.decode()
     assert b"0 failures" in res.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_strip_driver_from_a_plain_cpp_host(ranks):
+    """tests/cpp/strip_host_test.cpp: a g++-built C++ program (no Python, no torch, no HIP headers) forks `ranks`
+    processes that each own one strip on cuda:0 and call ststhip_strip_create / advance; ghost rows through a
+    shared-memory mailbox (the exchange callback); the pieces equal the single-strip run bit for bit."""
+    binary = os.path.join(OUT, "strip_host_test")
+    if not os.path.exists(binary):
+        pytest.fail("build/tests/strip_host_test missing: run __graft_entry__.build()")
+    res = subprocess.run([binary, str(ranks)], capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stdout.decode() + res.stderr.decode()
+    assert b"0 cells differ" in res.stdout
