@@ -26,9 +26,10 @@ FAMILIES = {
               "x_fd_aos_k1t6p4", "x_fd_aos_k1t6p6", "x_fd_aos_k1t6p8", "x_fd_aos_k1t4p8", "x_fdg_k1t6_persist"]),
     "hotspot": (8192, "hotspot", ["hotspot", "hotspot_aos"],
                 ["x_hs_soa_k1t8_coop", "x_hs_soa_k1t16_coop", "x_hs_soa_k2t8_coop", "x_hs_aos_k2t8_coop",
-                 "x_hs_aos_k1t16_coop", "x_hs_soa_k1t8_persist"]),
+                 "x_hs_aos_k1t16_coop", "x_hs_soa_k1t8_persist", "x_hs_soa_k1t12p4", "x_hs_soa_k1t16p4"]),
     "hotspot64": (8192, "hotspot64", ["hotspot_f64", "hotspot_f64_aos"],
-                  ["x_h64_soa_k1t8_coop", "x_h64_soa_k1t12_coop", "x_h64_soa_k1t16_coop", "x_h64_aos_k1t8_coop"]),
+                  ["x_h64_soa_k1t8_coop", "x_h64_soa_k1t12_coop", "x_h64_soa_k1t16_coop", "x_h64_aos_k1t8_coop",
+                   "x_h64_soa_k1t12p4", "x_h64_soa_k1t12p2", "x_h64_soa_k1t16p2", "x_h64_soa_k1t6p4"]),
     "jacobi": (16384, "jacobi", ["jacobi5general"], ["x_j5_k4t8_coop", "x_j5_k2t8_coop", "x_j5_k2t16_coop",
                                                       "x_j5_k4t8_persist"]),
     "uniform": (16384, "uniform", ["x_ju_k3t12"], ["x_ju_k3t12_coop", "x_ju_k2t16_coop", "x_ju_k3t12_persist"]),
