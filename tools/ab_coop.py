@@ -29,7 +29,8 @@ FAMILIES = {
                  "x_hs_aos_k1t16_coop", "x_hs_soa_k1t8_persist", "x_hs_soa_k1t12p4", "x_hs_soa_k1t16p4"]),
     "hotspot64": (8192, "hotspot64", ["hotspot_f64", "hotspot_f64_aos"],
                   ["x_h64_soa_k1t8_coop", "x_h64_soa_k1t12_coop", "x_h64_soa_k1t16_coop", "x_h64_aos_k1t8_coop",
-                   "x_h64_soa_k1t12p4", "x_h64_soa_k1t12p2", "x_h64_soa_k1t16p2", "x_h64_soa_k1t6p4"]),
+                   "x_h64_soa_k1t12p4", "x_h64_soa_k1t12p2", "x_h64_soa_k1t16p2", "x_h64_soa_k1t6p4",
+                   "x_h64_soa_k2t8p2", "x_h64_soa_k2t8p4", "x_h64_soa_k2t6p2", "x_h64_soa_k2t4p4"]),
     "jacobi": (16384, "jacobi", ["jacobi5general"], ["x_j5_k4t8_coop", "x_j5_k2t8_coop", "x_j5_k2t16_coop",
                                                       "x_j5_k4t8_persist"]),
     "uniform": (16384, "uniform", ["x_ju_k3t12"], ["x_ju_k3t12_coop", "x_ju_k2t16_coop", "x_ju_k3t12_persist"]),
