@@ -39,6 +39,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md, chip-level parameters)
+# what a plain device-to-device copy of a 1 GiB buffer reaches on this hardware (read + write bytes over time;
+# tools/microbench/hbm_pattern.hip, profiles/r02_hbm_pattern.txt: 4.9-5.5 TB/s): the attainable ceiling
+HBM_COPY_GBS = 5400.0
 BYTES_PER_CELL_UPDATE = 8  # 2 * sizeof(float) * n_subiterations (scripts/benchmark-common.jl:150-151)
 COEF = [0.2, 0.2, 0.2, 0.2, 0.2]  # examples/jacobi/scripts/benchmark.jl:44-45
 # VALU issue peak: plain fp32 wave-instructions per second and SIMD, measured on MI355X with every SIMD busy
@@ -187,6 +190,8 @@ def attach_counters(roofline, kernel_key, kernel_ms):
     traffic = counters["hbm_bytes_per_launch"]
     roofline["traffic"] = traffic
     roofline["fractions"]["physical_hbm"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    roofline["fractions"]["physical_hbm_of_measured_copy_rate"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_COPY_GBS
+    roofline["measured_copy_rate_GBps"] = HBM_COPY_GBS
     valu = counters.get("valu_wave_instructions_per_launch")
     if valu:
         busy_ms = valu * VALU_NS_PER_WAVE_INSTRUCTION * 1e-6 / N_SIMDS
