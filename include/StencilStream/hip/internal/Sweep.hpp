@@ -731,6 +731,16 @@ struct Sweep {
                         row_in = unsigned(j) < unsigned(g.grid_h);
 #pragma unroll
                     for (int k = 0; k < K; k++) {
+                        // stencil.id and grid_range are size_t in the API; their values fit 31 bits (checked at
+                        // launch).  Inside the grid -- always, in waves whose footprint lies inside it -- the
+                        // coordinates are not negative either: saying so lets a transition function's index
+                        // arithmetic (comparisons, conversions to float) stay 32 bits wide
+                        if constexpr (!EDGE) {
+                            __builtin_assume(j >= 0);
+                            __builtin_assume(x0 + k >= 0);
+                        }
+                        __builtin_assume(g.grid_h >= 0);
+                        __builtin_assume(g.grid_w >= 0);
                         StencilImpl st(sycl::id<2>(std::size_t(std::int64_t(j)),
                                                    std::size_t(std::int64_t(x0 + k))),
                                        sycl::range<2>(std::size_t(g.grid_h), std::size_t(g.grid_w)),
