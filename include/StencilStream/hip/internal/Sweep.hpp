@@ -395,6 +395,7 @@ struct SweepGeometry {
     std::int32_t tier_rows[max_tiers];
     std::int32_t tier_begin[max_tiers]; // first output row of the tier
     std::uint64_t pitch;                // elements between rows
+    std::uint32_t pitch32;              // the same (below 2^31, checked at launch)
     std::uint64_t iteration;            // generation index of the first level
     std::uint32_t xcd_remap;            // 1: give every XCD a contiguous range of the wave grid
     std::uint32_t last_chunk_early;     // 1: the last row chunk is dispatched second instead of last
@@ -610,7 +611,7 @@ struct Sweep {
             int yc = y < g.load_lo ? g.load_lo : y;
             yc = yc < y_load_end ? yc : y_load_end - 1;
             const std::size_t first =
-                std::size_t(yc - g.row_origin) * g.pitch + std::size_t(std::int64_t(x0));
+                row_offset(g, yc) + std::size_t(std::int64_t(x0));
             if constexpr (!EDGE) {
                 a.src.template load<K>(first, into);
             } else {
@@ -777,7 +778,7 @@ struct Sweep {
                 const int j = y - G; // row leaving the last level
                 if ((!FILLING || live) && j >= ya && j < yb && lane_stores) {
                     const std::size_t first =
-                        std::size_t(j - g.row_origin) * g.pitch + std::size_t(std::int64_t(x0));
+                        row_offset(g, j) + std::size_t(std::int64_t(x0));
                     if (!EDGE || vec_in) {
                         a.dst.template store<K, streaming_stores_for<F, SOA>(), skip_mask>(first, cur);
                     } else {
@@ -887,6 +888,13 @@ struct Sweep {
         } else {
             run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, nullptr);
         }
+    }
+
+    // Element offset of buffer row `y` (a global row the buffers hold): both factors fit 31 bits (checked at launch),
+    // so the 64-bit product is a 32 x 32 multiply -- two scalar instructions instead of the five of a 64 x 64 one,
+    // once per loaded and per stored row.
+    STST_DEVICE static std::size_t row_offset(SweepGeometry const &g, int y) {
+        return std::size_t(std::uint32_t(y - g.row_origin)) * std::size_t(g.pitch32);
     }
 
     // ---- persistent waves (see SweepGeometry) ----
@@ -1115,7 +1123,10 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
                                    SW::G, resident_blocks, int(waves_per_block));
     g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
     plan_tiers(g, int(out_end - out_begin));
+    if (dom.pitch >= (1ull << 31))
+        throw std::range_error("the pitch must be below 2^31 elements");
     g.pitch = dom.pitch;
+    g.pitch32 = std::uint32_t(dom.pitch);
     g.iteration = iteration;
     // measured (profiles/r01_xcd_remap.txt): 4 % fewer HBM reads, but no gain in time for these
     // VALU-bound kernels, so the remap is off unless asked for
