@@ -1119,10 +1119,38 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         if (ststhip_target_holds_constants() && env_int("STSTHIP_SKIP_CONSTANT_STORES", 1))
             kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, true>);
     g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW); // units: waves, or workgroups (coop)
-    g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), coop ? g.n_strips * waves_per_block : g.n_strips,
-                                   SW::G, resident_blocks, int(waves_per_block));
-    g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
-    plan_tiers(g, int(out_end - out_begin));
+    // a driver may leave a hole in the row range (ststhip_launch_row_hole): the two boundary bands of a row strip as
+    // ONE launch -- rows [out_begin, hole) and [hole end, out_end), the interior in between is another launch's
+    std::uint64_t hole_begin = 0, hole_end = 0;
+    ststhip_launch_row_hole(&hole_begin, &hole_end);
+    if (hole_begin < hole_end) {
+        if (hole_begin <= out_begin || hole_end >= out_end)
+            throw std::invalid_argument("the row hole must lie strictly inside the launch's row range");
+        const int part[2] = {int(hole_begin - out_begin), int(out_end - hole_end)};
+        const std::uint64_t part_begin[2] = {out_begin, hole_end};
+        const int wanted = pick_chunk_rows(std::max(part[0], part[1]), coop ? g.n_strips * waves_per_block : g.n_strips,
+                                           SW::G, resident_blocks, int(waves_per_block));
+        g.n_tiers = 2;
+        unsigned first = 0;
+        for (int t = 0; t < 2; t++) {
+            // equal chunks that tile the part exactly (a chunk must not reach into the hole)
+            int n = std::max(1, (part[t] + wanted / 2) / std::max(wanted, 1));
+            while (part[t] % n != 0)
+                n--;
+            g.tier_first[t] = first;
+            g.tier_rows[t] = part[t] / n;
+            g.tier_begin[t] = std::int32_t(part_begin[t]);
+            first += unsigned(n);
+        }
+        g.tier_first[2] = first;
+        g.n_chunks = first;
+        g.chunk_rows = std::max(g.tier_rows[0], g.tier_rows[1]);
+    } else {
+        g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), coop ? g.n_strips * waves_per_block : g.n_strips,
+                                       SW::G, resident_blocks, int(waves_per_block));
+        g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
+        plan_tiers(g, int(out_end - out_begin));
+    }
     if (dom.pitch >= (1ull << 31))
         throw std::range_error("the pitch must be below 2^31 elements");
     g.pitch = dom.pitch;
@@ -1154,7 +1182,7 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         const int rows = int(out_end - out_begin);
         int fine = env_int("STSTHIP_FINE_ROWS", 32);
         fine = round_up(std::max(fine, P_rows<SW>()), P_rows<SW>());
-        if (env_int("STSTHIP_PERSISTENT", 1) && rows >= 8 * fine) {
+        if (env_int("STSTHIP_PERSISTENT", 1) && rows >= 8 * fine && hole_begin == hole_end) {
             int cus = 256;
             ststhip_compute_units(&cus);
             std::uint32_t slots = std::uint32_t(cus) * std::uint32_t(std::max(resident_blocks, 1)) * waves_per_block /

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STSTHIP_ABI_VERSION 2
+#define STSTHIP_ABI_VERSION 3
 
 typedef enum {
     STSTHIP_OK = 0,
@@ -126,6 +126,13 @@ int ststhip_current_tdv_table(const void **base, uint64_t *first_iteration, uint
 /* A host that runs row-range sweeps side by side itself (the multi-GPU strip driver,
  * stencilstream_amd/dist.py) states their number here for the calling thread; 1 resets it. */
 int ststhip_set_launch_concurrency(int n_launches_side_by_side);
+/* A hole in the row range of the calling thread's next sweep launches: rows [*begin, *end) are left out, the
+ * launch produces the rows on both sides of them (begin == end: no hole, the state outside of a driver).  The
+ * strip driver sweeps the two boundary bands of a strip as one launch this way -- one dependent chain of band
+ * latency per pass instead of two (ststhip_strip_advance).  The setter is for hosts that drive ststhip_app_sweep
+ * themselves: set it, launch over [top of the upper band, end of the lower band), reset it with (0, 0). */
+int ststhip_launch_row_hole(uint64_t *begin, uint64_t *end);
+int ststhip_set_launch_row_hole(uint64_t begin, uint64_t end);
 /* Into how many row strips (1 or 2) a caller that advances `rows` x `width` cells of `app` for
  * `n_passes` launches should split them, each strip on its own stream and coupled to its
  * neighbours through halo-deep boundary bands only: the rule ststhip_run_passes applies to a whole

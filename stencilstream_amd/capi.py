@@ -181,6 +181,8 @@ def load():
         "ststhip_launch_concurrency": [],
         "ststhip_target_holds_constants": [],
         "ststhip_set_launch_concurrency": [C.c_int],
+        "ststhip_launch_row_hole": [C.POINTER(u64), C.POINTER(u64)],
+        "ststhip_set_launch_row_hole": [u64, u64],
         "ststhip_suggest_row_strips": [C.c_char_p, u64, u64, u64],
         "ststhip_scatter_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
         "ststhip_gather_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],

@@ -744,26 +744,46 @@ int ststhip_current_tdv_table(const void **base, uint64_t *first_iteration, uint
 static thread_local int g_launch_concurrency = 1;
 static thread_local int g_target_holds_constants = 0;
 int ststhip_launch_concurrency(void) { return g_launch_concurrency; }
+static thread_local std::uint64_t g_row_hole_begin = 0, g_row_hole_end = 0;
+int ststhip_launch_row_hole(uint64_t *begin, uint64_t *end) {
+    if (begin)
+        *begin = g_row_hole_begin;
+    if (end)
+        *end = g_row_hole_end;
+    return STSTHIP_OK;
+}
+int ststhip_set_launch_row_hole(uint64_t begin, uint64_t end) {
+    if (begin > end)
+        return fail(STSTHIP_ERR_INVALID, "row hole: begin after end");
+    g_row_hole_begin = begin;
+    g_row_hole_end = end;
+    return STSTHIP_OK;
+}
 int ststhip_target_holds_constants(void) { return g_target_holds_constants; }
 int ststhip_set_launch_concurrency(int n) {
     g_launch_concurrency = std::min(std::max(n, 1), 8);
     return STSTHIP_OK;
 }
 
-// Two row strips pay when one launch is at least ~1.7 residency rounds of waves (its tail then costs a
-// sizeable share and the other strip can fill it); below that the extra band launches cost more than
-// they win (measured: Jacobi 8192^2 -15 %, HotSpot 8192^2 +8 %, Jacobi 16384^2 +6 %).
+// Two row strips (two launches side by side, their boundary bands beside them on streams of their own) against one
+// launch per pass: measured over Jacobi (both forms), HotSpot fp32 / fp64, FDTD and the Game of Life at 1024 ... 16384
+// rows (profiles/r02_tune_strip_rule.txt), two strips win (+3 ... +18 %) when one launch of the whole grid would be
+// 1.22 or more times the wave slots of the chip in the launcher's own chunk model, and lose below (-3 ... -18 %).
+// A strip of a multi-GPU run that has neighbours sweeps two more bands per pass: there the second sub-strip pays
+// only from `outer_bands_threshold` on (8192 x 16384 Jacobi, 1.75: one sub-strip 4980, two 4640 Gcell-updates/s).
 static int suggest_row_strips(std::uint64_t rows, std::uint64_t width, std::uint32_t strip_width,
-                              std::uint64_t g_max, std::uint64_t n_passes) {
+                              std::uint64_t g_max, std::uint64_t n_passes, bool outer_bands = false) {
     int strips = stencil::hip::internal::env_int("STSTHIP_VIRTUAL_STRIPS", 0);
     if (strips <= 0) {
         strips = 1;
         if (n_passes >= 2 && strip_width > 0) {
+            const double threshold =
+                stencil::hip::internal::env_int("STSTHIP_TWO_STRIPS_PERMILLE", outer_bands ? 2000 : 1220) / 1000.0;
             const double n_cols = std::ceil(double(width) / strip_width);
             const double slots = double(rt().compute_units) * 16.0; // ~4 workgroups of 4 waves per CU
             const double chunk = std::sqrt(double(rows) * n_cols * (2.0 * double(g_max) + 8.0) / (0.5 * slots));
             const double waves = n_cols * double(rows) / std::max(chunk, 1.0);
-            if (waves >= 1.7 * slots)
+            if (waves >= threshold * slots)
                 strips = 2;
         } else if (n_passes >= 2 && rows >= 12288 && width >= 4096) {
             strips = 2;
@@ -1552,7 +1572,9 @@ int ststhip_strip_create(const char *app, const void *tf_params, const void *hal
     // the exchange stream has the highest priority as well: the send / receive kernels of RCCL are a workgroup or
     // two and would otherwise queue for wave slots behind the interiors they are meant to overlap with
     if (err == hipSuccess)
-        err = create_band_stream(&st->comm_stream);
+        err = stencil::hip::internal::env_int("STSTHIP_COMM_STREAM_PRIORITY", 1)
+                  ? create_band_stream(&st->comm_stream)
+                  : hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking);
     for (int set = 0; set < 2 && err == hipSuccess && rc == STSTHIP_OK; set++)
         for (unsigned p = 0; p < st->n_planes && rc == STSTHIP_OK; p++) {
             st->elem[p] = e->info.plane_elem_size[p];
@@ -1700,7 +1722,8 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     };
 
     // sub-strips of the owned rows, the rule of the single-GPU pass driver
-    int n_sub = suggest_row_strips(b - a, st->dom.global_width, e->info.strip_width, st->g_max, depths.size());
+    const bool neighbours = st->n_ranks > 1 || stencil::hip::internal::env_int("STSTHIP_STRIP_DEBUG_BANDS", 0) != 0;
+    int n_sub = suggest_row_strips(b - a, st->dom.global_width, e->info.strip_width, st->g_max, depths.size(), neighbours);
     n_sub = std::min(n_sub, 2);
     while (n_sub > 1 && (b - a) < std::uint64_t(n_sub) * 2 * std::max<std::uint64_t>(st->g_max, 1))
         n_sub--;
@@ -1718,10 +1741,15 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     std::vector<hipStream_t> lanes(n_sub, st->compute);
     for (int v = 1; v < n_sub; v++)
         lanes[v] = st->side[v - 1];
-    // boundary bands on highest-priority streams of their own, beside the interior of the same sub-strip and pass
-    // (the dependency rule of ststhip_run_passes; bands at the strip's ends additionally wait for the ghost rows)
+    // boundary bands on a highest-priority stream of their own, beside the interior of the same sub-strip and pass (the
+    // dependency rule of ststhip_run_passes; bands at the strip's ends additionally wait for the ghost rows).  A band
+    // is a dependent chain of 3g row steps per wave: 55-120 us beside a busy interior, and the two bands of a
+    // sub-strip follow each other in one stream.  STSTHIP_BANDS_APART=1 gives the top and the bottom band a stream
+    // each: measured 5-25 % slower (more streams than hardware queues; profiles/r02_thin_strips.txt), so it is off.
     const bool bands_beside = stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1) != 0;
-    while (bands_beside && int(st->band.size()) < n_sub) {
+    const bool bands_apart = bands_beside && stencil::hip::internal::env_int("STSTHIP_BANDS_APART", 0) != 0;
+    const bool bands_one_launch = stencil::hip::internal::env_int("STSTHIP_BANDS_ONE_LAUNCH", 1) != 0;
+    while (bands_beside && int(st->band.size()) < 2 * n_sub) {
         hipStream_t lane;
         if (create_band_stream(&lane) != hipSuccess)
             return hip_fail(hipErrorUnknown, "hipStreamCreateWithPriority");
@@ -1738,35 +1766,54 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     for (int v = 1; v < n_sub; v++)
         wait(lanes[v], begin);
     if (bands_beside)
-        for (int v = 0; v < n_sub; v++)
+        for (int v = 0; v < 2 * n_sub; v++)
             wait(st->band[v], begin);
     hipEvent_t ghosts_ready = nullptr;
     if (st->n_ranks > 1 && rc == STSTHIP_OK) {
         rc = strip_exchange(*st, st->current, depths[0] * hpg);
         ghosts_ready = record(st->comm_stream);
     }
-    std::vector<hipEvent_t> bands_done(n_sub, nullptr), interior_done(n_sub, nullptr);
+    struct BandEvents {
+        hipEvent_t top = nullptr, bottom = nullptr;
+    };
+    auto wait_bands = [&](hipStream_t who, BandEvents const &ev) {
+        wait(who, ev.top);
+        if (ev.bottom != ev.top)
+            wait(who, ev.bottom);
+    };
+    std::vector<BandEvents> bands_done(n_sub);
+    std::vector<hipEvent_t> interior_done(n_sub, nullptr);
     std::uint64_t iteration = iteration_offset;
     for (std::size_t i = 0; i < depths.size() && rc == STSTHIP_OK; i++) {
         const std::uint32_t depth = depths[i];
         const std::uint64_t g = depth * hpg;
         const void *const *src = const_cast<const void *const *>(st->planes[st->current]);
         void *const *dst = st->planes[st->current ^ 1];
-        std::vector<hipEvent_t> bands_now(n_sub, nullptr), interior_now(n_sub, nullptr);
+        std::vector<BandEvents> bands_now(n_sub);
+        std::vector<hipEvent_t> interior_now(n_sub, nullptr);
         for (int v = 0; v < n_sub && rc == STSTHIP_OK; v++) {
             const std::uint64_t va = bound[v], vb = bound[v + 1];
             hipStream_t lane = lanes[v];
-            hipStream_t bands_on = bands_beside ? st->band[v] : lane;
+            hipStream_t top_on = bands_beside ? st->band[2 * v] : lane;
+            hipStream_t bottom_on = bands_apart ? st->band[2 * v + 1] : top_on;
             const bool up = v > 0 || has_up;            // somebody above needs (and feeds) my top rows
             const bool down = v + 1 < n_sub || has_down;
-            if (v > 0)
-                wait(bands_on, bands_done[v - 1]);
-            if (v + 1 < n_sub)
-                wait(bands_on, bands_done[v + 1]);
-            if ((v == 0 && has_up) || (v == n_sub - 1 && has_down))
-                wait(bands_on, ghosts_ready);
-            if (bands_beside)
-                wait(bands_on, interior_done[v]);
+            // a band reads rows of the previous pass up to 2g into its own sub-strip (its interior, and in a thin
+            // sub-strip the other band) and g into the neighbour, and overwrites rows those launches read
+            for (hipStream_t on : {top_on, bottom_on}) {
+                if (v > 0)
+                    wait_bands(on, bands_done[v - 1]);
+                if (v + 1 < n_sub)
+                    wait_bands(on, bands_done[v + 1]);
+                if ((v == 0 && has_up) || (v == n_sub - 1 && has_down))
+                    wait(on, ghosts_ready);
+                if (bands_beside)
+                    wait(on, interior_done[v]);
+                if (bands_apart)
+                    wait_bands(on, bands_done[v]);
+                if (bottom_on == top_on)
+                    break;
+            }
             const std::uint64_t top_end = up ? std::min(va + g, vb) : va;
             const std::uint64_t bot_begin = down ? std::max(vb - std::min(g, vb - va), top_end) : vb;
             auto sweep = [&](std::uint64_t r0, std::uint64_t r1, hipStream_t on) {
@@ -1775,22 +1822,33 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
                     st->n_launches++;
                 }
             };
-            sweep(va, top_end, bands_on);
-            sweep(bot_begin, vb, bands_on);
-            bands_now[v] = record(bands_on);
+            if (bands_one_launch && n_sub == 1 && top_on == bottom_on && va < top_end && top_end < bot_begin && bot_begin < vb) {
+                // both bands as one launch with a hole where the interior is: one band latency per pass, not two, in
+                // front of the exchange for the next pass (a strip thin enough for one sub-strip is the case where
+                // band + exchange can take longer than the interior; with two sub-strips it measured 3 % slower)
+                g_row_hole_begin = top_end;
+                g_row_hole_end = bot_begin;
+                sweep(va, vb, top_on);
+                g_row_hole_begin = g_row_hole_end = 0;
+            } else {
+                sweep(va, top_end, top_on);
+                sweep(bot_begin, vb, bottom_on);
+            }
+            bands_now[v].top = record(top_on);
+            bands_now[v].bottom = bottom_on == top_on ? bands_now[v].top : record(bottom_on);
             if (bands_beside) {
                 // the interior reads the rows of this sub-strip's previous bands and, when this pass is shallower
                 // than the previous one, overwrites rows next to them that the neighbours' previous bands read
                 for (int w = std::max(v - 1, 0); w <= std::min(v + 1, n_sub - 1); w++)
-                    wait(lane, bands_done[w]);
+                    wait_bands(lane, bands_done[w]);
             }
             sweep(top_end, bot_begin, lane);
             if (bands_beside)
                 interior_now[v] = record(lane);
         }
         if (i + 1 < depths.size() && st->n_ranks > 1 && rc == STSTHIP_OK) {
-            wait(st->comm_stream, bands_now[0]);
-            wait(st->comm_stream, bands_now[n_sub - 1]);
+            wait_bands(st->comm_stream, bands_now[0]);
+            wait_bands(st->comm_stream, bands_now[n_sub - 1]);
             rc = strip_exchange(*st, st->current ^ 1, depths[i + 1] * hpg);
             ghosts_ready = record(st->comm_stream);
         }
@@ -1804,7 +1862,7 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     for (int v = 1; v < n_sub; v++)
         wait(st->compute, record(lanes[v]));
     if (bands_beside)
-        for (int v = 0; v < n_sub; v++)
+        for (int v = 0; v < 2 * n_sub; v++)
             wait(st->compute, record(st->band[v]));
     wait(st->compute, record(st->comm_stream));
     if (rc == STSTHIP_OK && blocking) {

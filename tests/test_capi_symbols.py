@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 
 def test_abi_version(built_lib):
-    assert built_lib.ststhip_abi_version() == 2
+    assert built_lib.ststhip_abi_version() == 3
 
 
 def test_registry_describes_the_apps(built_lib):

@@ -273,6 +273,52 @@ def test_sweep_row_ranges_compose(gpu, oracle):
     assert np.array_equal(bits(whole.cpu().numpy()), bits(want))
 
 
+def test_sweep_with_a_row_hole(gpu, oracle):
+    """ststhip_set_launch_row_hole: one launch produces the rows on both sides of a hole (the two boundary bands of a
+    row strip), bit-identical to the whole-grid sweep, and leaves the rows of the hole alone."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    lib = capi.load()
+    rng = np.random.default_rng(18)
+    s = torch.cuda.current_stream().cuda_stream
+    for W, T, halo, coef in ((700, 8, 0.25, [0.2, 0.21, 0.19, 0.22, 0.18]), (1300, 4, 0.0, [0.3, 0.1, 0.2, 0.15, 0.25])):
+        H = 400
+        grid = rng.random((H, W), dtype=np.float32)
+        p = capi.JacobiParams()
+        for i, c in enumerate(coef):
+            p.coef[i] = c
+        name = "jacobi5general"
+        g = T * capi.app_info(name).halo_depth_per_generation
+        src = torch.from_numpy(grid).cuda()
+        dom = capi.Domain(H, W, 0, H, W)
+        whole = torch.empty_like(src)
+        torch.cuda.synchronize()
+        capi.app_sweep(name, p, np.float32(halo).tobytes(), dom, [src.data_ptr()], [whole.data_ptr()], 0, H, 0, T, s)
+        for a, b, hole in ((40, 330, (40 + g, 330 - g)), (0, H, (13, 390)), (100, 200, (101, 199))):
+            dst = torch.full_like(src, float("nan"))
+            torch.cuda.synchronize()
+            capi.check(lib.ststhip_set_launch_row_hole(hole[0], hole[1]), "set hole")
+            try:
+                capi.app_sweep(name, p, np.float32(halo).tobytes(), dom, [src.data_ptr()], [dst.data_ptr()], a, b, 0, T, s)
+            finally:
+                capi.check(lib.ststhip_set_launch_row_hole(0, 0), "reset hole")
+            torch.cuda.synchronize()
+            assert torch.isnan(dst[:a]).all() and torch.isnan(dst[b:]).all() and torch.isnan(dst[hole[0]:hole[1]]).all()
+            assert torch.equal(dst[a:hole[0]].view(torch.int32), whole[a:hole[0]].view(torch.int32))
+            assert torch.equal(dst[hole[1]:b].view(torch.int32), whole[hole[1]:b].view(torch.int32))
+        want = oracle.jacobi("Jacobi5General", coef, grid, T, halo=halo, n_threads=8)
+        assert np.array_equal(bits(whole.cpu().numpy()), bits(want))
+    # a hole that is not strictly inside the range is refused
+    capi.check(lib.ststhip_set_launch_row_hole(0, 10), "set hole")
+    try:
+        with pytest.raises(capi.StsthipError):
+            capi.app_sweep("jacobi5general", p, np.float32(0).tobytes(), dom, [src.data_ptr()], [dst.data_ptr()], 0, H, 0, 4, s)
+    finally:
+        capi.check(lib.ststhip_set_launch_row_hole(0, 0), "reset hole")
+
+
 def test_scatter_gather_round_trip(gpu):
     import torch
 

@@ -1,0 +1,18 @@
+#!/bin/bash
+# One rank of a multi-GPU run on one GPU (two bands per pass, no exchange): both bands as one launch with a row hole
+# (STSTHIP_BANDS_ONE_LAUNCH=1) against two launches in the band stream.
+run() {
+  env STSTHIP_STRIP_DEBUG_BANDS=1 "$@" python bench.py --strip-domain --rows-per-gpu $ROWS --steps 4 --warmup 1 --no-cpu-baseline --no-verify 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('rows $ROWS', '$*', '| Gcell/s', round(d['value'], 1), 'ms_per_step', round(d['ms_per_step'], 3))"
+}
+for ROWS in 2048 4096 8192; do
+  for i in 1 2; do
+  run STSTHIP_BANDS_ONE_LAUNCH=0
+  run STSTHIP_BANDS_ONE_LAUNCH=1
+  done
+  run STSTHIP_BANDS_ONE_LAUNCH=1 STSTHIP_VIRTUAL_STRIPS=1
+  run STSTHIP_BANDS_ONE_LAUNCH=1 STSTHIP_VIRTUAL_STRIPS=2
+  run STSTHIP_BANDS_ONE_LAUNCH=0 STSTHIP_VIRTUAL_STRIPS=2
+done

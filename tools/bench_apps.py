@@ -36,6 +36,11 @@ def hotspot_params(n):
     return capi.HotspotParams(float(f32(1) / rx), float(f32(1) / ry), float(f32(1) / rz), float(step / cap))
 
 
+def dims(rows, cols):
+    """Grid of a configuration; BENCH_APPS_ROWS / BENCH_APPS_COLS override it (strip-rule sweeps)."""
+    return int(os.environ.get("BENCH_APPS_ROWS", rows)), int(os.environ.get("BENCH_APPS_COLS", cols))
+
+
 def run(app, params, halo, planes_a, planes_b, H, W, gens, stream, reps=3):
     dom = capi.Domain(H, W, 0, H, W)
     a = [t.data_ptr() for t in planes_a]
@@ -61,21 +66,21 @@ def main():
     out = []
     for name in which:
         if name == "jacobi":
-            app, H, W, gens = "jacobi5general", 16384, 16384, 240
+            app, (H, W), gens = "jacobi5general", dims(16384, 16384), 240
             p = capi.JacobiParams()
             for i in range(5):
                 p.coef[i] = 0.2
             halo = np.float32(0).tobytes()
             pa, pb = [torch.rand(H, W, device=dev)], [torch.empty(H, W, device=dev)]
         elif name == "jacobi_general":
-            app, H, W, gens = "jacobi5general", 16384, 16384, 240
+            app, (H, W), gens = "jacobi5general", dims(16384, 16384), 240
             p = capi.JacobiParams()
             for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
                 p.coef[i] = c
             halo = np.float32(0).tobytes()
             pa, pb = [torch.rand(H, W, device=dev)], [torch.empty(H, W, device=dev)]
         elif name in ("hotspot", "hotspot_aos"):
-            app, H, W, gens = name, 8192, 8192, 200
+            app, (H, W), gens = name, dims(8192, 8192), 200
             p = hotspot_params(H)
             halo = np.zeros(2, np.float32).tobytes()
             if name == "hotspot":
@@ -88,7 +93,7 @@ def main():
                 cells[..., 0] = 30.0
                 pa, pb = [cells], [torch.empty_like(cells)]
         elif name in ("hotspot_f64", "hotspot_f64_aos") or name.startswith("x_h64_"):
-            app, H, W, gens = name, 8192, 8192, (240 if name.startswith("x_h64_") else 200)
+            app, (H, W), gens = name, dims(8192, 8192), (240 if name.startswith("x_h64_") else 200)
             p32 = hotspot_params(H)
             p = capi.HotspotParamsF64(p32.Rx_1, p32.Ry_1, p32.Rz_1, p32.Cap_1)
             halo = np.zeros(2, np.float64).tobytes()
@@ -102,7 +107,7 @@ def main():
                 cells[..., 0] = 30.0
                 pa, pb = [cells], [torch.empty_like(cells)]
         elif name in ("fdtd", "fdtd_aos", "fdtd_grouped"):
-            app, H, W, gens = {"fdtd": "fdtd_coef", "fdtd_aos": "fdtd_coef_aos", "fdtd_grouped": "fdtd_coef_grouped"}[name], 4608, 4608, 120
+            app, (H, W), gens = {"fdtd": "fdtd_coef", "fdtd_aos": "fdtd_coef_aos", "fdtd_grouped": "fdtd_coef_grouped"}[name], dims(4608, 4608), 120
             p = capi.FdtdParams(dt=8.1e-19, t_0=3e-13, tau=1e-13, omega=7.5e14, cutoff_iteration=10 ** 9,
                                 detect_iteration=0, source_radius_squared=100.0, source_r=H / 2, source_c=W / 2,
                                 source_distance_bound=100.0 - 2 * (H / 2) ** 2, double_center_rc=float(H))
@@ -120,7 +125,7 @@ def main():
                 cells = torch.rand(H, W, 8, device=dev) * 1e-3
                 pa, pb = [cells], [torch.empty_like(cells)]
         elif name == "conway":
-            app, H, W, gens = "conway", 16384, 16384, 200
+            app, (H, W), gens = "conway", dims(16384, 16384), 200
             p = capi.NoParams()
             halo = b"\0"
             pa = [(torch.rand(H, W, device=dev) < 0.35).to(torch.uint8)]
