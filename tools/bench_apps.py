@@ -72,8 +72,8 @@ def main():
                 p.coef[i] = 0.2
             halo = np.float32(0).tobytes()
             pa, pb = [torch.rand(H, W, device=dev)], [torch.empty(H, W, device=dev)]
-        elif name == "jacobi_general":
-            app, (H, W), gens = "jacobi5general", dims(16384, 16384), 240
+        elif name in ("jacobi_general", "jacobi_general_persistent"):
+            app, (H, W), gens = ("jacobi5general" if name == "jacobi_general" else "jacobi5general_persistent"), dims(16384, 16384), 240
             p = capi.JacobiParams()
             for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
                 p.coef[i] = c
