@@ -154,12 +154,36 @@ class StencilUpdate {
         }
     }
 
+    // SweepTuning's generic rule sizes the pipeline by the cell alone.  A transition function with a lot of state of
+    // its own (FDTD's RenderResolver: sixteen ring bounds and material sets compared per cell) can need far more
+    // registers; the compiler then builds the deep kernels with spills to scratch, and they run several times slower
+    // than a shallower one (render example, 4608^2: T = 8: 54, T = 4: 69, T = 2: 176 Gcell-updates/s).  So: the
+    // deepest compiled depth whose kernel has no scratch, asked of the code object once per instantiation.
+    static int spill_free_depth() {
+        static const int depth = [] {
+            if (internal::env_int("STSTHIP_ALLOW_SPILLING_DEPTHS", 0))
+                return int(SweepTuning<F, on_planes>::max_generations);
+            return probe_depth<SweepTuning<F, on_planes>::max_generations>();
+        }();
+        return depth;
+    }
+    template <int T> static int probe_depth() {
+        using Tuning = SweepTuning<F, on_planes>;
+        const void *kernel = reinterpret_cast<const void *>(
+            &internal::sweep_kernel<internal::SweepOf<F, on_planes, T, inline_tdv>, Tuning::min_waves_per_simd>);
+        std::size_t scratch = 0;
+        if constexpr (T > 1)
+            if (ststhip_kernel_scratch_bytes(kernel, &scratch) == STSTHIP_OK && scratch > 0)
+                return probe_depth<T / 2>();
+        return T;
+    }
+
     // All passes of one call, from `source` planes into `target` planes.
     void run_passes(ststhip_domain const &dom, Planes const &source, Planes const &target,
                     ststhip_stream stream) {
         ststhip_sweep_desc desc = {};
         desc.n_planes = Planes::n_planes;
-        desc.max_generations = SweepTuning<F, on_planes>::max_generations;
+        desc.max_generations = std::uint32_t(spill_free_depth());
         desc.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
         desc.strip_width = std::uint32_t(internal::SweepOf<F, on_planes>::OW_PER_WAVE);
         for (int f = 0; f < Planes::n_planes; f++)

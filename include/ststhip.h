@@ -108,6 +108,12 @@ int ststhip_launch(const void *function, unsigned grid_x, unsigned grid_y, unsig
 int ststhip_occupancy(const void *function, unsigned block_threads, size_t shared_bytes,
                       int *blocks_per_cu);
 
+/* Bytes of scratch (private memory: register spills, dynamically indexed locals) per work-item of kernel
+ * `function`, from the code object.  The C++ templates use it to leave out temporal-blocking depths whose kernel the
+ * compiler could only build with spills (hip/StencilUpdate.hpp: a user's transition function may need far more
+ * registers than its cell size suggests). */
+int ststhip_kernel_scratch_bytes(const void *function, size_t *bytes_per_work_item);
+
 /* How many sweep launches the pass driver currently keeps in flight side by side (1 outside of
  * ststhip_run_passes).  The launcher sizes its row chunks with it: concurrent launches share the
  * chip and hide each other's tails, so longer chunks (fewer warm-up rows) pay. */

@@ -178,6 +178,7 @@ def load():
         "ststhip_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
         "ststhip_launch": [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, pp, sz, vp],
         "ststhip_occupancy": [vp, C.c_uint, sz, C.POINTER(C.c_int)],
+        "ststhip_kernel_scratch_bytes": [vp, C.POINTER(sz)],
         "ststhip_launch_concurrency": [],
         "ststhip_target_holds_constants": [],
         "ststhip_set_launch_concurrency": [C.c_int],

@@ -713,6 +713,17 @@ int ststhip_launch(const void *function, unsigned grid_x, unsigned grid_y, unsig
     return STSTHIP_OK;
 }
 
+int ststhip_kernel_scratch_bytes(const void *function, size_t *bytes_per_work_item) {
+    if (!function || !bytes_per_work_item)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    hipFuncAttributes attr;
+    HIP_TRY(hipFuncGetAttributes(&attr, function));
+    *bytes_per_work_item = attr.localSizeBytes;
+    return STSTHIP_OK;
+}
+
 int ststhip_occupancy(const void *function, unsigned block_threads, size_t shared_bytes,
                       int *blocks_per_cu) {
     if (!function || !blocks_per_cu || block_threads == 0)

@@ -260,6 +260,74 @@ template <typename Strategy> static void test_tdv_strategy(const char *name) {
     REQUIRE(same);
 }
 
+// A transition function that carries a lot of state of its own (the shape of FDTD's RenderResolver: a ladder of bounds,
+// each with a set of coefficients, compared for every cell in both sub-iterations).  SweepTuning's generic rule would
+// sweep its 16-byte cell eight generations deep; the compiler can only build that kernel with spills, so the update
+// leaves that depth out (StencilUpdate::spill_free_depth) -- whatever depth runs, the result is the cpu backend's.
+struct LadderCell {
+    float a, b, c, d;
+};
+struct Ladder {
+    using Cell = LadderCell;
+    using TimeDependentValue = std::monostate;
+    static constexpr std::size_t stencil_radius = 1;
+    static constexpr std::size_t n_subiterations = 2;
+    static constexpr int n_steps = 20;
+    float bound[n_steps];
+    float gain[n_steps][4];
+    std::monostate get_time_dependent_value(std::size_t) const { return {}; }
+    LadderCell operator()(Stencil<LadderCell, 1> const &s) const {
+        LadderCell me = s[0][0];
+        const float dr = float(s.id[0]) - float(s.grid_range[0] / 2), dc = float(s.id[1]) - float(s.grid_range[1] / 2);
+        const float score = dr * dr + dc * dc;
+        int step = n_steps - 1;
+        for (int i = n_steps - 1; i >= 0; i--)
+            if (score <= bound[i])
+                step = i;
+        if (s.subiteration == 0) {
+            me.a = gain[step][0] * me.a + gain[step][1] * (s[0][-1].c - s[0][0].c);
+            me.b = gain[step][0] * me.b + gain[step][1] * (s[-1][0].c - s[0][0].c);
+        } else {
+            me.c = gain[step][2] * me.c + gain[step][3] * ((s[0][1].a - s[0][0].a) + (s[1][0].b - s[0][0].b));
+            me.d += me.c * me.c;
+        }
+        return me;
+    }
+};
+
+static void test_state_heavy_functor() {
+    const std::size_t h = 190, w = 275;
+    Ladder f;
+    for (int i = 0; i < Ladder::n_steps; i++) {
+        f.bound[i] = float((i + 1) * (i + 1) * 40);
+        for (int k = 0; k < 4; k++)
+            f.gain[i][k] = 0.25f + 0.03125f * float((i * 4 + k) % 13);
+    }
+    hip::Grid<LadderCell> grid(h, w);
+    cpu::Grid<LadderCell> host_grid(h, w);
+    {
+        hip::Grid<LadderCell>::GridAccessor<sycl::access::mode::read_write> ac(grid);
+        cpu::Grid<LadderCell>::GridAccessor<sycl::access::mode::read_write> hc(host_grid);
+        for (std::size_t r = 0; r < h; r++)
+            for (std::size_t c = 0; c < w; c++)
+                hc[r][c] = ac[r][c] = LadderCell{float((r * 7 + c) % 32) * 0.03125f, float((r + c * 5) % 16) * 0.0625f,
+                                                 float((r * 3 + c * 11) % 64) * 0.015625f, 0.0f};
+    }
+    hip::StencilUpdate<Ladder> update({.transition_function = f, .halo_value = LadderCell{0.5f, 0.25f, 0.125f, 0.0f},
+                                       .n_iterations = 23, .blocking = true});
+    cpu::StencilUpdate<Ladder> reference({.transition_function = f, .halo_value = LadderCell{0.5f, 0.25f, 0.125f, 0.0f},
+                                          .n_iterations = 23, .blocking = true});
+    hip::Grid<LadderCell> out = update(grid);
+    cpu::Grid<LadderCell> want = reference(host_grid);
+    hip::Grid<LadderCell>::GridAccessor<sycl::access::mode::read> ac(out);
+    cpu::Grid<LadderCell>::GridAccessor<sycl::access::mode::read> wc(want);
+    bool same = true;
+    for (std::size_t r = 0; r < h; r++)
+        for (std::size_t c = 0; c < w; c++)
+            same = same && std::memcmp(&ac[r][c], &wc[r][c], sizeof(LadderCell)) == 0;
+    REQUIRE(same);
+}
+
 static void test_tdv_strategies() {
     test_tdv_strategy<tdv::single_pass::PrecomputeOnHostStrategy>("PrecomputeOnHost");
     test_tdv_strategy<tdv::single_pass::PrecomputeOnDeviceStrategy>("PrecomputeOnDevice");
@@ -281,5 +349,6 @@ int main() {
     test_zero_iterations_alias();
     test_split_request_on_fat_cells();
     test_constant_fields_hint();
+    test_state_heavy_functor();
     return finish("hip_api_test");
 }
