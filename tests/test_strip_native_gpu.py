@@ -119,6 +119,30 @@ def _rank(rank, world, port, result_dir):
         launches, exchanges = strip.counters()
         assert exchanges >= 5
         strip.close()
+    # two planes (HotSpot) and the Game of Life on words of four cells: the middle rank of three sweeps both of its
+    # boundary bands as one launch with a row hole
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(91)
+    cells = np.zeros((H, W), dtype=O.HOTSPOT_CELL)
+    cells["temp"] = 320 + 10 * rng.random((H, W), dtype=np.float32)
+    cells["power"] = rng.random((H, W), dtype=np.float32) * 0.01
+    hp = O.hotspot_params(H, W)
+    strip = capi.Strip("hotspot", capi.HotspotParams(hp.Rx_1, hp.Ry_1, hp.Rz_1, hp.Cap_1), bytes(8), H, W, rank, world,
+                       exchange=exchange)
+    strip.upload(0, np.ascontiguousarray(cells["temp"][strip.row_begin:strip.row_end]))
+    strip.upload(1, np.ascontiguousarray(cells["power"][strip.row_begin:strip.row_end]))
+    strip.warm_up()
+    strip.advance(0, 21, blocking=True)
+    np.save(os.path.join(result_dir, f"hotspot{rank}.npy"), strip.download(0, np.float32))
+    strip.close()
+    life = (rng.random((H, W)) < 0.35).astype(np.uint8)
+    strip = capi.Strip("conway", capi.NoParams(), b"\0", H, W, rank, world, exchange=exchange)
+    strip.upload(0, life[strip.row_begin:strip.row_end])
+    strip.warm_up()
+    strip.advance(0, 23, blocking=True)
+    np.save(os.path.join(result_dir, f"conway{rank}.npy"), strip.download(0, np.uint8))
+    strip.close()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -139,6 +163,16 @@ def test_strips_of_several_processes_on_one_gpu(gpu, oracle, tmp_path, world):
         want = oracle.jacobi("Jacobi5General", coef, grid, 37, halo=halo, n_threads=8)
         got = np.concatenate([np.load(tmp_path / f"{tag}{r}.npy") for r in range(world)], axis=0)
         assert np.array_equal(bits(got), bits(want)), tag
+    rng = np.random.default_rng(91)  # the same draws as the ranks
+    cells = np.zeros((1000, 900), dtype=oracle.HOTSPOT_CELL)
+    cells["temp"] = 320 + 10 * rng.random((1000, 900), dtype=np.float32)
+    cells["power"] = rng.random((1000, 900), dtype=np.float32) * 0.01
+    want = oracle.hotspot(oracle.hotspot_params(1000, 900), cells, 21, n_threads=8)
+    got = np.concatenate([np.load(tmp_path / f"hotspot{r}.npy") for r in range(world)], axis=0)
+    assert np.array_equal(bits(got), bits(np.ascontiguousarray(want["temp"]))), "hotspot"
+    life = (rng.random((1000, 900)) < 0.35).astype(np.uint8)
+    got = np.concatenate([np.load(tmp_path / f"conway{r}.npy") for r in range(world)], axis=0)
+    assert np.array_equal(got, oracle.conway(life, 23, n_threads=8)), "conway"
 
 
 def _rccl_rank(rank, world, id_file, result_dir):
