@@ -206,6 +206,35 @@ def test_fdtd_bit_exact(gpu, oracle, shape, layout):
     assert np.abs(want["hz_sum"]).max() > 0 and np.abs(want["hz"]).max() > 0
 
 
+@pytest.mark.parametrize("layout", ["grouped", "aos"])
+def test_fdtd_through_the_strip_driver(gpu, oracle, layout):
+    """ststhip_strip_advance with a function that has sub-iterations and time-dependent values, two calls with an
+    iteration offset (the values of a launch come from the host here: the strip driver builds no device table)."""
+    from stencilstream_amd import capi, update as U
+
+    H, W = 300, 222
+    po, pc, cells = fdtd_setup(oracle, H, W)
+    halo = np.zeros((), dtype=U.FDTD_CELL)
+    strip = capi.Strip(U.fdtd(pc, layout=layout).app, pc, halo.tobytes(), H, W, 0, 1)
+    if layout == "aos":
+        strip.upload(0, cells.view(np.uint8).reshape(H, W * 32))
+    else:
+        raw = cells.view(np.float32).reshape(H, W, 8)
+        strip.upload(0, np.ascontiguousarray(raw[:, :, :4]).reshape(H, W * 4))
+        strip.upload(1, np.ascontiguousarray(raw[:, :, 4:]).reshape(H, W * 4))
+    strip.advance(0, 30)
+    strip.advance(30, 11, blocking=True)
+    want = oracle.fdtd(po, cells, 41, n_threads=8)
+    if layout == "aos":
+        got = strip.download(0, np.uint8).reshape(H, W, 32).view(np.float32).reshape(H, W, 8)
+    else:
+        got = np.concatenate([strip.download(0, np.float32).reshape(H, W, 4), strip.download(1, np.float32).reshape(H, W, 4)],
+                             axis=2)
+    strip.close()
+    assert np.array_equal(bits(got), bits(want.view(np.float32).reshape(H, W, 8)))
+    assert np.abs(want["hz"]).max() > 0
+
+
 @pytest.mark.parametrize("split", [True, False], ids=["soa", "aos"])
 def test_fdtd_reference_functor_frames_on_gpu(gpu, oracle, split):
     """The frames the reference's unchanged examples/fdtd sources wrote (tests/golden/fdtd, see
