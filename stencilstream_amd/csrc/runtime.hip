@@ -781,7 +781,7 @@ int ststhip_set_launch_concurrency(int n) {
 // rows (profiles/r02_tune_strip_rule.txt), two strips win (+3 ... +18 %) when one launch of the whole grid would be
 // 1.22 or more times the wave slots of the chip in the launcher's own chunk model, and lose below (-3 ... -18 %).
 // A strip of a multi-GPU run that has neighbours sweeps two more bands per pass: there the second sub-strip pays
-// only from `outer_bands_threshold` on (8192 x 16384 Jacobi, 1.75: one sub-strip 4980, two 4640 Gcell-updates/s).
+// only from 1.5 on (Jacobi 4096 x 16384, 1.24: one sub-strip 3990, two 4020; 8192 x 16384, 1.75: 4990 / 5350).
 static int suggest_row_strips(std::uint64_t rows, std::uint64_t width, std::uint32_t strip_width,
                               std::uint64_t g_max, std::uint64_t n_passes, bool outer_bands = false) {
     int strips = stencil::hip::internal::env_int("STSTHIP_VIRTUAL_STRIPS", 0);
@@ -789,7 +789,7 @@ static int suggest_row_strips(std::uint64_t rows, std::uint64_t width, std::uint
         strips = 1;
         if (n_passes >= 2 && strip_width > 0) {
             const double threshold =
-                stencil::hip::internal::env_int("STSTHIP_TWO_STRIPS_PERMILLE", outer_bands ? 2000 : 1220) / 1000.0;
+                stencil::hip::internal::env_int("STSTHIP_TWO_STRIPS_PERMILLE", outer_bands ? 1500 : 1220) / 1000.0;
             const double n_cols = std::ceil(double(width) / strip_width);
             const double slots = double(rt().compute_units) * 16.0; // ~4 workgroups of 4 waves per CU
             const double chunk = std::sqrt(double(rows) * n_cols * (2.0 * double(g_max) + 8.0) / (0.5 * slots));
@@ -1580,10 +1580,11 @@ int ststhip_strip_create(const char *app, const void *tf_params, const void *hal
     st->dom.row_origin = st->row_origin;
     st->dom.local_rows = st->local_rows;
     hipError_t err = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
-    // the exchange stream has the highest priority as well: the send / receive kernels of RCCL are a workgroup or
-    // two and would otherwise queue for wave slots behind the interiors they are meant to overlap with
+    // the exchange stream has normal priority: as a third highest-priority stream beside the band streams of two
+    // sub-strips it cost 8-30 % (streams of one priority share few hardware queues, and a band waiting for its events
+    // holds up whatever sits behind it in the same queue: profiles/r02_thin_strips.txt section 7)
     if (err == hipSuccess)
-        err = stencil::hip::internal::env_int("STSTHIP_COMM_STREAM_PRIORITY", 1)
+        err = stencil::hip::internal::env_int("STSTHIP_COMM_STREAM_PRIORITY", 0)
                   ? create_band_stream(&st->comm_stream)
                   : hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking);
     for (int set = 0; set < 2 && err == hipSuccess && rc == STSTHIP_OK; set++)
@@ -1760,7 +1761,9 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     const bool bands_beside = stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1) != 0;
     const bool bands_apart = bands_beside && stencil::hip::internal::env_int("STSTHIP_BANDS_APART", 0) != 0;
     const bool bands_one_launch = stencil::hip::internal::env_int("STSTHIP_BANDS_ONE_LAUNCH", 1) != 0;
-    while (bands_beside && int(st->band.size()) < 2 * n_sub) {
+    // (only as many as are used: streams are dealt onto a few hardware queues in creation order, idle ones included)
+    const int n_band_streams = bands_apart ? 2 * n_sub : n_sub;
+    while (bands_beside && int(st->band.size()) < n_band_streams) {
         hipStream_t lane;
         if (create_band_stream(&lane) != hipSuccess)
             return hip_fail(hipErrorUnknown, "hipStreamCreateWithPriority");
@@ -1777,7 +1780,7 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     for (int v = 1; v < n_sub; v++)
         wait(lanes[v], begin);
     if (bands_beside)
-        for (int v = 0; v < 2 * n_sub; v++)
+        for (int v = 0; v < n_band_streams; v++)
             wait(st->band[v], begin);
     hipEvent_t ghosts_ready = nullptr;
     if (st->n_ranks > 1 && rc == STSTHIP_OK) {
@@ -1805,7 +1808,7 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
         for (int v = 0; v < n_sub && rc == STSTHIP_OK; v++) {
             const std::uint64_t va = bound[v], vb = bound[v + 1];
             hipStream_t lane = lanes[v];
-            hipStream_t top_on = bands_beside ? st->band[2 * v] : lane;
+            hipStream_t top_on = bands_beside ? st->band[bands_apart ? 2 * v : v] : lane;
             hipStream_t bottom_on = bands_apart ? st->band[2 * v + 1] : top_on;
             const bool up = v > 0 || has_up;            // somebody above needs (and feeds) my top rows
             const bool down = v + 1 < n_sub || has_down;
@@ -1873,7 +1876,7 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     for (int v = 1; v < n_sub; v++)
         wait(st->compute, record(lanes[v]));
     if (bands_beside)
-        for (int v = 0; v < 2 * n_sub; v++)
+        for (int v = 0; v < n_band_streams; v++)
             wait(st->compute, record(st->band[v]));
     wait(st->compute, record(st->comm_stream));
     if (rc == STSTHIP_OK && blocking) {
