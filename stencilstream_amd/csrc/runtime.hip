@@ -97,6 +97,8 @@ static std::map<hipStream_t, std::vector<hipStream_t>> &band_streams() {
     return streams;
 }
 static hipError_t create_band_stream(hipStream_t *stream) {
+    if (!stencil::hip::internal::env_int("STSTHIP_BAND_STREAM_PRIORITY", 1)) // A/B: bands on normal-priority streams
+        return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
         greatest = 0;
