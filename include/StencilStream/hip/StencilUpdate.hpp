@@ -97,6 +97,25 @@ class StencilUpdate {
     std::size_t get_n_processed_cells() const { return n_processed_cells; }
     double get_walltime() const { return walltime; }
 
+    // For drivers other than operator() (hip/StripUpdate.hpp: one strip of a grid cut over several GPUs): the launch
+    // callback of this instantiation -- its context is a pointer to this object, which must stay where it is -- and
+    // the description ststhip_run_passes / ststhip_strip_create_custom plan their passes with.
+    static ststhip_sweep_fn launch_entry() { return &sweep_trampoline; }
+    static ststhip_sweep_desc sweep_description() {
+        ststhip_sweep_desc desc = {};
+        desc.n_planes = Planes::n_planes;
+        desc.max_generations = std::uint32_t(spill_free_depth());
+        desc.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
+        desc.strip_width = std::uint32_t(internal::SweepOf<F, on_planes>::OW_PER_WAVE);
+        for (int f = 0; f < Planes::n_planes; f++)
+            desc.plane_elem_size[f] = Planes::elem_size(f);
+        return desc;
+    }
+    static constexpr bool sweeps_on_planes = on_planes;
+    static constexpr int n_planes = Planes::n_planes;
+    static std::size_t plane_elem_size(int f) { return Planes::elem_size(f); }
+    static std::size_t plane_elem_offset(int f) { return Planes::elem_offset(f); }
+
     // Sum of the sweep kernels' device time in seconds (HIP events around every launch); needs
     // Params::profiling, which also makes the call synchronous.
     double get_kernel_runtime() const { return kernel_runtime; }
@@ -181,13 +200,7 @@ class StencilUpdate {
     // All passes of one call, from `source` planes into `target` planes.
     void run_passes(ststhip_domain const &dom, Planes const &source, Planes const &target,
                     ststhip_stream stream) {
-        ststhip_sweep_desc desc = {};
-        desc.n_planes = Planes::n_planes;
-        desc.max_generations = std::uint32_t(spill_free_depth());
-        desc.halo_depth_per_generation = std::uint32_t(F::stencil_radius * F::n_subiterations);
-        desc.strip_width = std::uint32_t(internal::SweepOf<F, on_planes>::OW_PER_WAVE);
-        for (int f = 0; f < Planes::n_planes; f++)
-            desc.plane_elem_size[f] = Planes::elem_size(f);
+        ststhip_sweep_desc desc = sweep_description();
         // one device table of time-dependent values per call: filled by the host, or by the device
         void *device_values = nullptr;
         if constexpr (has_tdv && !inline_tdv) {

@@ -339,6 +339,12 @@ typedef int (*ststhip_exchange_fn)(void *ctx, int n_planes, const void *const *s
 int ststhip_strip_create(const char *app, const void *tf_params, const void *halo_cell, uint64_t total_rows,
                          uint64_t width, int rank, int n_ranks, ststhip_comm comm, ststhip_exchange_fn exchange,
                          void *exchange_ctx, ststhip_strip *strip);
+/* The same strip for a sweep that is not in the registry: the launch callback and description a caller would hand to
+ * ststhip_run_passes (the C++ templates instantiate the kernel for a user's transition function in their own
+ * translation unit: StencilStream/hip/StripUpdate.hpp).  The buffers are the planes `desc` describes. */
+int ststhip_strip_create_custom(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc, uint64_t total_rows,
+                                uint64_t width, int rank, int n_ranks, ststhip_comm comm,
+                                ststhip_exchange_fn exchange, void *exchange_ctx, ststhip_strip *strip);
 int ststhip_strip_destroy(ststhip_strip strip);
 /* global rows [row_begin, row_end) this strip owns */
 int ststhip_strip_rows(ststhip_strip strip, uint64_t *row_begin, uint64_t *row_end);

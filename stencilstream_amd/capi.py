@@ -201,6 +201,7 @@ def load():
         "ststhip_comm_destroy": [vp],
         "ststhip_comm_exchange_rows": [vp, C.c_int, pp, pp, pp, pp, C.POINTER(sz), sz, vp],
         "ststhip_strip_create": [C.c_char_p, vp, vp, u64, u64, C.c_int, C.c_int, vp, vp, vp, pp],
+        "ststhip_strip_create_custom": [vp, vp, vp, u64, u64, C.c_int, C.c_int, vp, vp, vp, pp],
         "ststhip_strip_destroy": [vp],
         "ststhip_strip_rows": [vp, C.POINTER(u64), C.POINTER(u64)],
         "ststhip_strip_plane": [vp, C.c_uint, pp, C.POINTER(sz)],

@@ -1525,6 +1525,61 @@ int strip_exchange(Strip &st, int set, std::uint64_t g) {
 }
 } // namespace
 
+namespace {
+// the part of strip creation that does not depend on where the sweep comes from: geometry, streams, buffers
+int finish_strip(Strip *st, const ststhip_domain *dom, ststhip_strip *strip) {
+    const ststhip_sweep_desc &d = st->resolved.desc;
+    if (d.n_planes == 0 || d.n_planes > 16 || d.max_generations == 0) {
+        delete st;
+        return fail(STSTHIP_ERR_INVALID, "bad sweep description");
+    }
+    st->n_planes = d.n_planes;
+    st->g_max = std::uint64_t(d.max_generations) * d.halo_depth_per_generation;
+    std::uint64_t thinnest = st->total_rows;
+    for (int r = 0; r < st->n_ranks; r++) {
+        std::uint64_t a, b;
+        strip_bounds(st->total_rows, st->n_ranks, r, a, b);
+        thinnest = std::min(thinnest, b - a);
+    }
+    if (st->n_ranks > 1 && thinnest < 2 * st->g_max) {
+        delete st;
+        return fail(STSTHIP_ERR_INVALID, "strips are thinner than two halo depths: use fewer ranks or a larger grid");
+    }
+    st->row_origin = std::int64_t(st->row_begin) - std::int64_t(st->g_max);
+    st->local_rows = (st->row_end - st->row_begin) + 2 * st->g_max;
+    st->dom = *dom; // width and pitch possibly in words
+    st->dom.row_origin = st->row_origin;
+    st->dom.local_rows = st->local_rows;
+    int rc = STSTHIP_OK;
+    hipError_t err = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
+    // the exchange stream has normal priority: as a third highest-priority stream beside the band streams of two
+    // sub-strips it cost 8-30 % (streams of one priority share few hardware queues, and a band waiting for its events
+    // holds up whatever sits behind it in the same queue: profiles/r02_thin_strips.txt section 7)
+    if (err == hipSuccess)
+        err = stencil::hip::internal::env_int("STSTHIP_COMM_STREAM_PRIORITY", 0)
+                  ? create_band_stream(&st->comm_stream)
+                  : hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking);
+    for (int set = 0; set < 2 && err == hipSuccess && rc == STSTHIP_OK; set++)
+        for (unsigned p = 0; p < st->n_planes && rc == STSTHIP_OK; p++) {
+            st->elem[p] = d.plane_elem_size[p];
+            const std::size_t bytes = std::size_t(st->local_rows) * st->dom.pitch * st->elem[p];
+            rc = ststhip_malloc_async(&st->planes[set][p], bytes, st->compute);
+            if (rc == STSTHIP_OK)
+                err = hipMemsetAsync(st->planes[set][p], 0, bytes, st->compute);
+        }
+    if (err != hipSuccess)
+        rc = hip_fail(err, "strip set-up");
+    if (rc == STSTHIP_OK && (err = hipStreamSynchronize(st->compute)) != hipSuccess)
+        rc = hip_fail(err, "strip set-up");
+    if (rc != STSTHIP_OK) {
+        ststhip_strip_destroy(st);
+        return rc;
+    }
+    *strip = st;
+    return STSTHIP_OK;
+}
+} // namespace
+
 int ststhip_strip_create(const char *app, const void *tf_params, const void *halo_cell, uint64_t total_rows,
                          uint64_t width, int rank, int n_ranks, ststhip_comm comm, ststhip_exchange_fn exchange,
                          void *exchange_ctx, ststhip_strip *strip) {
@@ -1563,50 +1618,38 @@ int ststhip_strip_create(const char *app, const void *tf_params, const void *hal
         delete st;
         return rc;
     }
-    e = st->resolved.entry;
-    st->n_planes = e->info.n_planes;
-    st->g_max = std::uint64_t(e->info.max_generations) * e->info.halo_depth_per_generation;
-    std::uint64_t thinnest = total_rows;
-    for (int r = 0; r < n_ranks; r++) {
-        std::uint64_t a, b;
-        strip_bounds(total_rows, n_ranks, r, a, b);
-        thinnest = std::min(thinnest, b - a);
-    }
-    if (n_ranks > 1 && thinnest < 2 * st->g_max) {
-        delete st;
-        return fail(STSTHIP_ERR_INVALID, "strips are thinner than two halo depths: use fewer ranks or a larger grid");
-    }
-    st->row_origin = std::int64_t(st->row_begin) - std::int64_t(st->g_max);
-    st->local_rows = (st->row_end - st->row_begin) + 2 * st->g_max;
-    st->dom = *dom; // width and pitch possibly in words
-    st->dom.row_origin = st->row_origin;
-    st->dom.local_rows = st->local_rows;
-    hipError_t err = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
-    // the exchange stream has normal priority: as a third highest-priority stream beside the band streams of two
-    // sub-strips it cost 8-30 % (streams of one priority share few hardware queues, and a band waiting for its events
-    // holds up whatever sits behind it in the same queue: profiles/r02_thin_strips.txt section 7)
-    if (err == hipSuccess)
-        err = stencil::hip::internal::env_int("STSTHIP_COMM_STREAM_PRIORITY", 0)
-                  ? create_band_stream(&st->comm_stream)
-                  : hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking);
-    for (int set = 0; set < 2 && err == hipSuccess && rc == STSTHIP_OK; set++)
-        for (unsigned p = 0; p < st->n_planes && rc == STSTHIP_OK; p++) {
-            st->elem[p] = e->info.plane_elem_size[p];
-            const std::size_t bytes = std::size_t(st->local_rows) * st->dom.pitch * st->elem[p];
-            rc = ststhip_malloc_async(&st->planes[set][p], bytes, st->compute);
-            if (rc == STSTHIP_OK)
-                err = hipMemsetAsync(st->planes[set][p], 0, bytes, st->compute);
-        }
-    if (err != hipSuccess)
-        rc = hip_fail(err, "strip set-up");
-    if (rc == STSTHIP_OK && (err = hipStreamSynchronize(st->compute)) != hipSuccess)
-        rc = hip_fail(err, "strip set-up");
-    if (rc != STSTHIP_OK) {
-        ststhip_strip_destroy(st);
+    return finish_strip(st, dom, strip);
+}
+
+int ststhip_strip_create_custom(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc, uint64_t total_rows,
+                                uint64_t width, int rank, int n_ranks, ststhip_comm comm, ststhip_exchange_fn exchange,
+                                void *exchange_ctx, ststhip_strip *strip) {
+    if (!sweep || !desc || !strip || n_ranks < 1 || rank < 0 || rank >= n_ranks || width == 0)
+        return fail(STSTHIP_ERR_INVALID, "bad strip arguments");
+    if (n_ranks > 1 && !comm && !exchange)
+        return fail(STSTHIP_ERR_INVALID, "several strips need a communicator or an exchange callback");
+    if (int rc = ststhip_init(-1))
         return rc;
-    }
-    *strip = st;
-    return STSTHIP_OK;
+    Strip *st = new Strip;
+    st->rank = rank;
+    st->n_ranks = n_ranks;
+    st->comm = static_cast<Comm *>(comm);
+    st->exchange = exchange;
+    st->exchange_ctx = exchange_ctx;
+    st->total_rows = total_rows;
+    st->width = width;
+    strip_bounds(total_rows, n_ranks, rank, st->row_begin, st->row_end);
+    st->resolved.entry = nullptr; // the caller's sweep: no registry entry, no run window to maintain
+    st->resolved.trampoline = sweep;
+    st->resolved.ctx = ctx;
+    st->resolved.desc = *desc;
+    ststhip_domain whole;
+    whole.global_height = total_rows;
+    whole.global_width = width;
+    whole.pitch = width;
+    whole.row_origin = 0;
+    whole.local_rows = total_rows;
+    return finish_strip(st, &whole, strip);
 }
 
 int ststhip_strip_destroy(ststhip_strip strip) {
@@ -1708,12 +1751,12 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     Strip *st = static_cast<Strip *>(strip);
     if (!st)
         return fail(STSTHIP_ERR_INVALID, "null argument");
-    const AppEntry *e = st->resolved.entry;
-    const std::vector<std::uint32_t> depths = plan_depths(n_generations, e->info.max_generations);
+    const ststhip_sweep_desc &d = st->resolved.desc;
+    const std::vector<std::uint32_t> depths = plan_depths(n_generations, d.max_generations);
     if (depths.empty())
         return STSTHIP_OK;
     st->resolved.set_run(iteration_offset, n_generations);
-    const std::uint64_t hpg = e->info.halo_depth_per_generation;
+    const std::uint64_t hpg = d.halo_depth_per_generation;
     const std::uint64_t a = st->row_begin, b = st->row_end;
     int rc = STSTHIP_OK;
     std::vector<hipEvent_t> events;
@@ -1737,7 +1780,7 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
 
     // sub-strips of the owned rows, the rule of the single-GPU pass driver
     const bool neighbours = st->n_ranks > 1 || stencil::hip::internal::env_int("STSTHIP_STRIP_DEBUG_BANDS", 0) != 0;
-    int n_sub = suggest_row_strips(b - a, st->dom.global_width, e->info.strip_width, st->g_max, depths.size(), neighbours);
+    int n_sub = suggest_row_strips(b - a, st->dom.global_width, d.strip_width, st->g_max, depths.size(), neighbours);
     n_sub = std::min(n_sub, 2);
     while (n_sub > 1 && (b - a) < std::uint64_t(n_sub) * 2 * std::max<std::uint64_t>(st->g_max, 1))
         n_sub--;

@@ -39,3 +39,35 @@ def test_strip_driver_from_a_plain_cpp_host(ranks):
     res = subprocess.run([binary, str(ranks)], capture_output=True, timeout=600)
     assert res.returncode == 0, res.stdout.decode() + res.stderr.decode()
     assert b"0 cells differ" in res.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_strip_update_template_with_user_functors(tmp_path, ranks):
+    """tests/cpp/strip_template_test.hip: stencil::hip::StripUpdate -- USER transition functions (time-dependent values
+    and sub-iterations on AoS cells; a two-field cell on per-field planes) over `ranks` processes on cuda:0, ghost rows
+    through a mailbox file; the rows of all ranks equal the single-strip run, which the binary itself checks against
+    hip::StencilUpdate on the whole grid."""
+    import numpy as np
+
+    binary = os.path.join(OUT, "strip_template_test")
+    if not os.path.exists(binary):
+        pytest.fail("build/tests/strip_template_test missing: run __graft_entry__.build()")
+    size, ramp_at, plate_at, height, width = (int(x) for x in subprocess.check_output([binary, "layout"]).split())
+
+    def run(n, path):
+        with open(path, "wb") as f:
+            f.truncate(size)
+        procs = [subprocess.Popen([binary, str(r), str(n), str(path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                 for r in range(n)]
+        for p in procs:
+            out, _ = p.communicate(timeout=600)
+            assert p.returncode == 0, out.decode()
+        return np.fromfile(path, dtype=np.uint8)
+
+    many = run(ranks, tmp_path / "mailbox_many")
+    one = run(1, tmp_path / "mailbox_one")
+    cells = height * width
+    assert np.array_equal(many[ramp_at:ramp_at + 4 * cells], one[ramp_at:ramp_at + 4 * cells]), "Ramp"
+    assert np.array_equal(many[plate_at:plate_at + 8 * cells], one[plate_at:plate_at + 8 * cells]), "Conduction"
+    assert one[ramp_at:ramp_at + 4 * cells].view(np.float32).std() > 0
