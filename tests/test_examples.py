@@ -112,6 +112,22 @@ def test_jacobi_hip_bit_exact(tmp_path, oracle, variant):
 
 
 @pytest.mark.gpu
+def test_jacobi_strips_example_single_rank(tmp_path, oracle):
+    """examples/jacobi_strips.cpp (hip::StripUpdate with the reference's Jacobi5General; one process per GPU over RCCL):
+    as one rank its output file equals the oracle -- and so the unchanged single-GPU example's.  More ranks need a GPU
+    each; the same driver with several strips is covered by tests/test_cpp_api.py (mailbox exchange)."""
+    binary = exe("jacobi_strips_hip")
+    coef = ["0.2", "0.21", "0.19", "0.22", "0.18"]
+    H, W, its = 300, 700, 29
+    out_file = tmp_path / "out.bin"
+    res = run([binary, str(H), str(W), str(its), str(out_file)] + coef)
+    assert b"Walltime:" in res.stdout and b"Strips: 1" in res.stdout
+    got = np.fromfile(out_file, dtype=np.float32).reshape(H, W)
+    want = oracle.jacobi("Jacobi5General", [float(c) for c in coef], oracle.jacobi_init(H, W), its, halo=0.0, n_threads=8)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_jacobi_hip_show_config():
     out = run([exe("jacobi_Jacobi5General_hip"), "show-config"]).stdout.decode()
     cfg = json.loads(out)
