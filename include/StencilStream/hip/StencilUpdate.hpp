@@ -111,6 +111,16 @@ class StencilUpdate {
             desc.plane_elem_size[f] = Planes::elem_size(f);
         return desc;
     }
+    // the same with the host-side source of the time-dependent values: a driver builds one device table per call
+    // from it (the strip driver; operator() decides per strategy in run_passes)
+    static ststhip_sweep_desc sweep_description_with_host_values() {
+        ststhip_sweep_desc desc = sweep_description();
+        if constexpr (has_tdv && !inline_tdv) {
+            desc.tdv_size = sizeof(TDV);
+            desc.fill_tdv = &fill_values;
+        }
+        return desc;
+    }
     static constexpr bool sweeps_on_planes = on_planes;
     static constexpr int n_planes = Planes::n_planes;
     static std::size_t plane_elem_size(int f) { return Planes::elem_size(f); }
@@ -138,6 +148,12 @@ class StencilUpdate {
     }
 
   private:
+    static void fill_values(void *ctx, std::uint64_t offset, std::uint64_t n, void *values) {
+        StencilUpdate const *self = static_cast<StencilUpdate const *>(ctx);
+        for (std::uint64_t i = 0; i < n; i++)
+            static_cast<TDV *>(values)[i] = self->params.transition_function.get_time_dependent_value(offset + i);
+    }
+
     // One launch, called back by the runtime's pass driver (ststhip_run_passes): evaluates the
     // time-dependent values of the launch's generations on the host and starts the sweep kernel that
     // was instantiated for F in this translation unit.
@@ -218,11 +234,7 @@ class StencilUpdate {
                     desc.tdv_device_table = device_values;
                 }
             } else {
-                desc.fill_tdv = [](void *ctx, std::uint64_t offset, std::uint64_t n, void *values) {
-                    StencilUpdate const *self = static_cast<StencilUpdate const *>(ctx);
-                    for (std::uint64_t i = 0; i < n; i++)
-                        static_cast<TDV *>(values)[i] = self->params.transition_function.get_time_dependent_value(offset + i);
-                };
+                desc.fill_tdv = &fill_values;
             }
         }
         ststhip_run_info info = {};

@@ -36,7 +36,7 @@ class StripUpdate {
                 ststhip_exchange_fn exchange = nullptr, void *exchange_ctx = nullptr)
         : update(std::make_unique<Update>(params)), width(width) {
         internal::ensure_runtime(params.device.hip_index());
-        const ststhip_sweep_desc desc = Update::sweep_description();
+        const ststhip_sweep_desc desc = Update::sweep_description_with_host_values();
         internal::check(ststhip_strip_create_custom(Update::launch_entry(), update.get(), &desc, total_rows, width, rank,
                                                     n_ranks, comm, exchange, exchange_ctx, &strip),
                         "ststhip_strip_create_custom");

@@ -1820,7 +1820,23 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     const bool has_up = st->rank > 0 || pretend, has_down = st->rank + 1 < st->n_ranks || pretend;
     g_launch_concurrency = n_sub;
 
-    hipEvent_t begin = record(st->compute); // everything queued so far: a previous advance, uploads
+    // one device table of time-dependent values for the whole call, as in ststhip_run_passes (the launches then take
+    // their values from it instead of evaluating them on the host one launch at a time)
+    void *tdv_table = nullptr;
+    if (d.tdv_size > 0 && d.fill_tdv && rc == STSTHIP_OK) {
+        const std::size_t bytes = std::size_t(d.tdv_size) * n_generations;
+        rc = ststhip_malloc_async(&tdv_table, bytes, st->compute);
+        if (rc == STSTHIP_OK) {
+            std::vector<unsigned char> values(bytes);
+            d.fill_tdv(st->resolved.ctx, iteration_offset, n_generations, values.data());
+            ordered(hipMemcpyAsync(tdv_table, values.data(), bytes, hipMemcpyHostToDevice, st->compute), "hipMemcpyAsync");
+            g_tdv_table = tdv_table;
+            g_tdv_first = iteration_offset;
+            g_tdv_count = n_generations;
+            g_tdv_size = d.tdv_size;
+        }
+    }
+    hipEvent_t begin = record(st->compute); // everything queued so far: a previous advance, uploads, the table
     wait(st->comm_stream, begin);
     for (int v = 1; v < n_sub; v++)
         wait(lanes[v], begin);
@@ -1917,6 +1933,8 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
         iteration += depth;
     }
     g_launch_concurrency = 1;
+    g_tdv_table = nullptr;
+    g_tdv_count = 0;
     // the compute stream is the one callers synchronise with
     for (int v = 1; v < n_sub; v++)
         wait(st->compute, record(lanes[v]));
@@ -1929,6 +1947,8 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
         if (err != hipSuccess)
             rc = hip_fail(err, "hipStreamSynchronize");
     }
+    if (tdv_table)
+        ststhip_free_async(tdv_table, st->compute); // every stream has been joined into the compute stream above
     for (hipEvent_t ev : events)
         (void)hipEventDestroy(ev); // released once they have completed
     return rc;

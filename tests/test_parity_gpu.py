@@ -209,7 +209,7 @@ def test_fdtd_bit_exact(gpu, oracle, shape, layout):
 @pytest.mark.parametrize("layout", ["grouped", "aos"])
 def test_fdtd_through_the_strip_driver(gpu, oracle, layout):
     """ststhip_strip_advance with a function that has sub-iterations and time-dependent values, two calls with an
-    iteration offset (the values of a launch come from the host here: the strip driver builds no device table)."""
+    iteration offset (one device table of values per call, as in ststhip_run_passes)."""
     from stencilstream_amd import capi, update as U
 
     H, W = 300, 222
