@@ -1084,10 +1084,19 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     constexpr bool coop = cooperative_for<F, SOA>();
     if (out_end <= out_begin || dom.global_width == 0)
         return;
+    // a driver may leave a hole in the row range (ststhip_launch_row_hole): the two boundary bands of a row strip as
+    // ONE launch -- rows [out_begin, hole) and [hole end, out_end), the interior in between is another launch's
+    std::uint64_t hole_begin = 0, hole_end = 0;
+    ststhip_launch_row_hole(&hole_begin, &hole_end);
     if constexpr (has_narrow_form<F, SOA>()) {
-        // grids that cannot fill the chip with this shape: the same function on the narrowest lanes
+        // grids that cannot fill the chip with this shape: the same function on the narrowest lanes.  So are launches
+        // of a few rows -- the boundary bands of row strips: a band is a dependent chain of 3g row steps per wave that
+        // runs beside a busy interior, and with one cell per lane instead of several a step is that much shorter
+        // (the next pass of two strips and the ghost-row exchange wait for it)
         static const std::uint64_t narrow_form_cells = std::uint64_t(env_int("STSTHIP_NARROW_FORM_KCELLS", 20000)) * 1000;
-        if (dom.global_height * dom.global_width <= narrow_form_cells) {
+        static const std::uint64_t narrow_band_rows = std::uint64_t(env_int("STSTHIP_NARROW_BAND_ROWS", 0));
+        const std::uint64_t launch_rows = (out_end - out_begin) - (hole_end - hole_begin);
+        if (dom.global_height * dom.global_width <= narrow_form_cells || launch_rows <= narrow_band_rows) {
             launch_sweep<NarrowForm<F>, SOA, T, INLINE_TDV>(NarrowForm<F>(f), halo, tdv, dom, src, dst, out_begin, out_end,
                                                             iteration, stream);
             return;
@@ -1119,10 +1128,6 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         if (ststhip_target_holds_constants() && env_int("STSTHIP_SKIP_CONSTANT_STORES", 1))
             kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, true>);
     g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW); // units: waves, or workgroups (coop)
-    // a driver may leave a hole in the row range (ststhip_launch_row_hole): the two boundary bands of a row strip as
-    // ONE launch -- rows [out_begin, hole) and [hole end, out_end), the interior in between is another launch's
-    std::uint64_t hole_begin = 0, hole_end = 0;
-    ststhip_launch_row_hole(&hole_begin, &hole_end);
     if (hole_begin < hole_end) {
         if (hole_begin <= out_begin || hole_end >= out_end)
             throw std::invalid_argument("the row hole must lie strictly inside the launch's row range");
