@@ -396,6 +396,31 @@ int ststhip_init(int device) {
     r.compute_units = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
     r.up = true;
+    // The streams the pass driver adds to the runtime's own stream -- one side stream and two highest-priority band
+    // streams -- are created and used once here: a stream (and the hardware queue behind it) costs milliseconds on
+    // first use, 15-20 ms for the three, which would otherwise land in the first update call
+    // (a one-shot 1000-generation run of the unchanged jacobi example: 0.121 -> 0.10 s; profiles/r02_short_runs.txt).
+    if (stencil::hip::internal::env_int("STSTHIP_PREPARE_STREAMS", 1)) {
+        std::vector<hipStream_t> made;
+        auto &side = side_streams()[r.stream];
+        auto &band = band_streams()[r.stream];
+        hipStream_t extra = nullptr;
+        if (side.empty() && hipStreamCreateWithFlags(&extra, hipStreamNonBlocking) == hipSuccess)
+            side.push_back(extra);
+        while (band.size() < 2 && create_band_stream(&extra) == hipSuccess)
+            band.push_back(extra);
+        made.insert(made.end(), side.begin(), side.end());
+        made.insert(made.end(), band.begin(), band.end());
+        made.push_back(r.stream);
+        void *word = nullptr;
+        if (hipMalloc(&word, 256) == hipSuccess) {
+            for (hipStream_t st : made)
+                (void)hipMemsetAsync(word, 0, 4, st);
+            for (hipStream_t st : made)
+                (void)hipStreamSynchronize(st);
+            (void)hipFree(word);
+        }
+    }
     return STSTHIP_OK;
 }
 
