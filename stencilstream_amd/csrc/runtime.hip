@@ -396,11 +396,13 @@ int ststhip_init(int device) {
     r.compute_units = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
     r.up = true;
-    // The streams the pass driver adds to the runtime's own stream -- one side stream and two highest-priority band
-    // streams -- are created and used once here: a stream (and the hardware queue behind it) costs milliseconds on
-    // first use, 15-20 ms for the three, which would otherwise land in the first update call
-    // (a one-shot 1000-generation run of the unchanged jacobi example: 0.121 -> 0.10 s; profiles/r02_short_runs.txt).
-    if (stencil::hip::internal::env_int("STSTHIP_PREPARE_STREAMS", 1)) {
+    // STSTHIP_PREPARE_STREAMS=1: the streams the pass driver adds to the runtime's own stream -- one side stream and two
+    // highest-priority band streams -- are created and used once here: a stream (and the hardware queue behind it)
+    // costs milliseconds on first use, 15-20 ms for the three, which otherwise land in the first update call (a
+    // one-shot 1000-generation run of the unchanged jacobi example: 0.121 -> 0.096 s; profiles/r02_short_runs.txt).
+    // Off by default: for a caller that brings its OWN stream (bench.py, the Python API) these would be four idle
+    // streams in front of its own on the few hardware queues, and its strips collide (bench.py 6500 -> 4280).
+    if (stencil::hip::internal::env_int("STSTHIP_PREPARE_STREAMS", 0)) {
         std::vector<hipStream_t> made;
         auto &side = side_streams()[r.stream];
         auto &band = band_streams()[r.stream];

@@ -292,6 +292,7 @@ def test_sweep_row_ranges_compose(gpu, oracle):
             src = whole[lo:hi].contiguous()  # owned rows + ghost rows
             dst = torch.full_like(src, float("nan"))
             dom = capi.Domain(H, W, lo, hi - lo, W)
+            torch.cuda.synchronize()  # stream 0 below = the library's own stream, unordered with torch's kernels above
             capi.app_sweep("jacobi5general", p, np.float32(0.0).tobytes(), dom, [src.data_ptr()], [dst.data_ptr()],
                            a, b, 0, T, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
@@ -360,13 +361,17 @@ def test_scatter_gather_round_trip(gpu):
         offs = [dt.fields[n][1] for n in dt.names]
         sizes = [dt.fields[n][0].itemsize for n in dt.names]
         planes = [torch.zeros(n_cells * s, dtype=torch.uint8, device="cuda") for s in sizes]
-        s = torch.cuda.current_stream().cuda_stream
+        s = torch.cuda.current_stream().cuda_stream  # 0 = the library's own stream, unordered with torch's
+        torch.cuda.synchronize()
         capi.scatter_fields(aos.data_ptr(), dt.itemsize, n_cells, offs, sizes, [t.data_ptr() for t in planes], s)
+        torch.cuda.synchronize()
         host = raw.view(dt)
         for name, t in zip(dt.names, planes):
             assert np.array_equal(t.cpu().numpy(), np.ascontiguousarray(host[name]).view(np.uint8)), name
         back = torch.zeros_like(aos)
+        torch.cuda.synchronize()
         capi.gather_fields(back.data_ptr(), dt.itemsize, n_cells, offs, sizes, [t.data_ptr() for t in planes], s)
+        torch.cuda.synchronize()
         assert torch.equal(back, aos)
 
 
