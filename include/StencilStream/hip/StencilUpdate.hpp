@@ -196,7 +196,7 @@ class StencilUpdate {
     // deepest compiled depth whose kernel has no scratch, asked of the code object once per instantiation.
     static int spill_free_depth() {
         static const int depth = [] {
-            if (internal::env_int("STSTHIP_ALLOW_SPILLING_DEPTHS", 0))
+            if (internal::options().allow_spilling_depths)
                 return int(SweepTuning<F, on_planes>::max_generations);
             return probe_depth<SweepTuning<F, on_planes>::max_generations>();
         }();

@@ -20,13 +20,13 @@
 //    inter-wave synchronisation); chunks overlap by G rows for pipeline warm-up.
 //  * HBM rows are read as one K-wide vector per lane (1 KiB per wave and row for fp32, K = 4),
 //    software-prefetched P rows ahead, and written the same way.
-//  * Cooperative strips (SweepTuning::cooperative, for transition functions that read no west / east
-//    neighbour in the southernmost stencil row): the four waves of a workgroup take four ADJACENT strips
-//    without overlap and hand each other the edge columns of every pipeline level through LDS, one
-//    workgroup barrier per row.  Only the workgroup as a whole overlaps its neighbours by G columns, so a
-//    wave produces (256*K - 2G)/4 instead of 64*K - 2G columns of the 64*K it loads and computes (FDTD:
-//    58 instead of 40 of 64).  This is the LDS halo exchange north_star asks for, placed where the
-//    redundancy was: replaces the per-work-item neighbour loads of cuda/StencilUpdate.hpp:346-396.
+//  * Staged sweeps (SweepTuning::stages = W > 1): the W waves of a workgroup share ONE column strip as a software
+//    pipeline over the levels -- stage s runs levels [s*S/W, (s+1)*S/W), takes its input rows from stage s-1 and
+//    hands its output rows to stage s+1 through an LDS ring (batches of P rows, one workgroup barrier per batch).
+//    A wave then keeps the register window of S/W levels only, a row chunk is W times longer for the same number of
+//    waves (the 2G warm-up rows are paid once per W waves), and a launch of few rows -- the boundary band of a row
+//    strip -- is a dependent chain of S/W instead of S levels per row.  This is where north_star's "LDS tiles" sit
+//    in this design: between the stages of the temporal pipeline, not under the column halo.
 #pragma once
 #include "../../Concepts.hpp"
 #include "../../Stencil.hpp"
@@ -206,29 +206,6 @@ template <int DppCtrl, typename T> STST_DEVICE inline T lane_shift(T const &valu
     __builtin_memcpy(&shifted, &words, sizeof(T));
     return shifted;
 }
-// The same shift, but the lane without a source lane (lane 0 for wave_shr, lane 63 for wave_shl) receives
-// `edge` instead (DPP with bound_ctrl = 0 leaves the destination, preloaded with `edge`, untouched there).
-template <int DppCtrl, typename T> STST_DEVICE inline T lane_shift_or(T const &value, T const &edge) {
-    static_assert(std::is_trivially_copyable_v<T>);
-    constexpr int n_words = int((sizeof(T) + 3) / 4);
-    struct Words {
-        int w[n_words];
-    } words = {}, old = {};
-    __builtin_memcpy(&words, &value, sizeof(T));
-    __builtin_memcpy(&old, &edge, sizeof(T));
-#pragma unroll
-    for (int i = 0; i < n_words; i++)
-        words.w[i] = __builtin_amdgcn_update_dpp(old.w[i], words.w[i], DppCtrl, 0xf, 0xf, false);
-    T shifted;
-    __builtin_memcpy(&shifted, &words, sizeof(T));
-    return shifted;
-}
-template <typename T> STST_DEVICE inline T from_west_lane_or(T const &v, T const &edge) {
-    return lane_shift_or<0x138>(v, edge);
-}
-template <typename T> STST_DEVICE inline T from_east_lane_or(T const &v, T const &edge) {
-    return lane_shift_or<0x130>(v, edge);
-}
 // value of lane-1 (data moves towards higher lanes): DPP wave_shr:1
 template <typename T> STST_DEVICE inline T from_west_lane(T const &v) { return lane_shift<0x138>(v); }
 // value of lane+1: DPP wave_shl:1
@@ -261,17 +238,17 @@ template <typename Cell, bool SOA> constexpr int cell_words() {
 //   prefetch_rows (P)    rows loaded ahead; must be a multiple of 2*radius
 //   interior_variant     also build the check-free code path for waves away from the grid edge
 //   min_waves_per_simd   occupancy the register allocator must allow (second __launch_bounds__ argument)
+//   stages               (optional member, default 1) waves of a workgroup that share ONE column strip as a software
+//                        pipeline over the levels: stage s runs levels [s*S/stages, (s+1)*S/stages) and hands every row
+//                        it emits to stage s+1 through an LDS ring (see the head of Sweep.hpp).  Depths whose level
+//                        count is not a multiple of `stages` run with the largest divisor that is (12 generations in
+//                        4 stages; its halvings 6 and 3 in 3, 1 in 1).
 //   streaming_stores     (optional member) store results with the non-temporal hint (streaming_stores_for below)
-//   cooperative          (optional member, default false) the four waves of a workgroup take adjacent strips and
-//                        exchange their edge columns through LDS (see the head of Sweep.hpp).  ONLY for transition
-//                        functions that never read stencil[radius][dc] with dc != 0 ... more precisely: no cell of
-//                        the southernmost stencil row other than the columns of the lane's own cells, i.e. for
-//                        radius 1 neither stencil[1][-1] nor stencil[1][1] (5-point and "north-heavy" stencils).
-//                        The southernmost row is the one a level receives in the same step, before the
-//                        neighbour wave's copy can have crossed the barrier.
 //   trapezoid_fill       (optional member) skip the levels that are not due yet while a wave's pipeline fills;
 //                        default: cells of up to four words per generation (measured: Jacobi +3 %, HotSpot
 //                        +5 %, Conway +4 %, FDTD -2..-8 %: profiles/r01_ab_trapezoid_fill.txt)
+//   narrow_form          (optional member, default true) grids too small to fill the chip may be swept with the
+//                        one-cell-per-lane form of the same function (NarrowForm below); explicit shapes say false
 template <typename F, bool SOA> struct SweepTuning {
   private:
     static constexpr int R = int(F::stencil_radius);
@@ -316,12 +293,27 @@ template <typename F, bool SOA> struct SweepTuning {
         return p;
     }
 
+    // Stages (Sweep.hpp head): four waves per column strip where the levels divide by four, else two, as long as
+    // the row rings between the stages stay within 40 KiB of LDS per workgroup (four workgroups per CU).  Measured on
+    // MI355X (profiles/r03_tune_staged.txt), full grids / 2048-row strips: Jacobi5General +3 % / +14 %, the packed
+    // Game of Life +29 %, HotSpot +18 %, FDTD +13...23 %; launches of a few rows (boundary bands) run a third as long.
+    static constexpr int ring_bytes(int w, int k, int p) {
+        return (w - 1) * 2 * p * 64 * k * int((sizeof(typename F::Cell) + 3) / 4) * 4;
+    }
+    static constexpr int pick_w(int t, int k, int p) {
+        for (int w : {4, 2})
+            if ((t * NS) % w == 0 && ring_bytes(w, k, p) <= 40 * 1024)
+                return w;
+        return 1;
+    }
+
   public:
     static constexpr int cells_per_lane = pick_k();
     static constexpr int max_generations = pick_t(cells_per_lane);
     static constexpr int prefetch_rows = pick_p(max_generations, cells_per_lane);
     static constexpr bool interior_variant = (W * NS <= 16);
     static constexpr int min_waves_per_simd = 1;
+    static constexpr int stages = pick_w(max_generations, cells_per_lane, prefetch_rows);
 };
 
 namespace internal {
@@ -334,6 +326,33 @@ namespace internal {
 template <typename F> struct NarrowForm : public F {
     NarrowForm(F const &f) : F(f) {}
 };
+
+template <typename F, bool SOA> constexpr int stages_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::stages; })
+        return SweepTuning<F, SOA>::stages;
+    else
+        return 1;
+}
+
+template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })
+        return SweepTuning<F, SOA>::trapezoid_fill;
+    else
+        return cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 4;
+}
+
+// Non-temporal stores of the results (SweepTuning<F, SOA>::streaming_stores, optional member).  Measured
+// (profiles/r01_ab_nt_stores.txt): +1.2..1.6 % Jacobi, +1..5 % HotSpot fp32, +2..4 % HotSpot fp64 on planes; but
+// -8 % FDTD on planes, -1 % FDTD / HotSpot fp64 as AoS and -3 % for the packed Game of Life -- the kernels that are
+// bound by HBM or store narrow rows pay for partial lines that L2 no longer merges.  Default: cells of up to two
+// 32-bit words per generation that are at least one word wide.
+template <typename F, bool SOA> constexpr bool streaming_stores_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::streaming_stores; })
+        return SweepTuning<F, SOA>::streaming_stores;
+    else
+        return sizeof(typename F::Cell) >= 4 &&
+               cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 2;
+}
 } // namespace internal
 
 template <typename F, bool SOA> struct SweepTuning<internal::NarrowForm<F>, SOA> {
@@ -342,20 +361,10 @@ template <typename F, bool SOA> struct SweepTuning<internal::NarrowForm<F>, SOA>
     static constexpr int prefetch_rows = SweepTuning<F, SOA>::prefetch_rows;
     static constexpr bool interior_variant = SweepTuning<F, SOA>::interior_variant;
     static constexpr int min_waves_per_simd = SweepTuning<F, SOA>::min_waves_per_simd;
-    static constexpr bool cooperative = false;
-    static constexpr bool trapezoid_fill = [] {
-        if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })
-            return SweepTuning<F, SOA>::trapezoid_fill;
-        else
-            return internal::cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 4;
-    }();
-    static constexpr bool streaming_stores = [] {
-        if constexpr (requires { SweepTuning<F, SOA>::streaming_stores; })
-            return SweepTuning<F, SOA>::streaming_stores;
-        else
-            return sizeof(typename F::Cell) >= 4 &&
-                   internal::cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 2;
-    }();
+    static constexpr int stages = internal::stages_for<F, SOA>();
+    static constexpr bool narrow_form = false;
+    static constexpr bool trapezoid_fill = internal::trapezoid_fill_for<F, SOA>();
+    static constexpr bool streaming_stores = internal::streaming_stores_for<F, SOA>();
 };
 
 namespace internal {
@@ -364,17 +373,18 @@ template <typename T> struct is_narrow_form : std::false_type {};
 template <typename F> struct is_narrow_form<NarrowForm<F>> : std::true_type {};
 
 // Does F have a narrower shape worth compiling?  Only functions whose default shape holds several cells per lane
-// and that are not swept cooperatively; the wave of the narrow shape must still produce columns at full depth.
+// (and whose tuning does not say `narrow_form = false`: an explicit shape is launched as it is); the wave of the
+// narrow shape must still produce columns at full depth.
 template <typename F, bool SOA> constexpr bool has_narrow_form() {
     if constexpr (is_narrow_form<F>::value) {
         return false;
     } else {
         constexpr int k = ceil_pow2(int(F::stencil_radius));
         constexpr int g = int(F::stencil_radius) * int(F::n_subiterations) * SweepTuning<F, SOA>::max_generations;
-        bool coop = false;
-        if constexpr (requires { SweepTuning<F, SOA>::cooperative; })
-            coop = SweepTuning<F, SOA>::cooperative;
-        return !coop && SweepTuning<F, SOA>::cells_per_lane > k && wave_size * k - 2 * round_up(g, k) >= 16 * k;
+        bool allowed = true;
+        if constexpr (requires { SweepTuning<F, SOA>::narrow_form; })
+            allowed = SweepTuning<F, SOA>::narrow_form;
+        return allowed && SweepTuning<F, SOA>::cells_per_lane > k && wave_size * k - 2 * round_up(g, k) >= 16 * k;
     }
 }
 
@@ -384,9 +394,9 @@ struct SweepGeometry {
     std::int32_t row_origin;            // global row of buffer row 0
     std::int32_t load_lo, load_hi;      // global rows present in the source buffers
     std::int32_t out_begin, out_end;    // global rows to produce
-    std::int32_t chunk_rows;            // rows of output per wave
-    std::uint32_t n_strips, n_chunks;   // wave grid
-    // The last waves of the grid (dispatched last) take shorter chunks, so that the ragged end of a
+    std::int32_t chunk_rows;            // rows of output per unit of the wave grid
+    std::uint32_t n_strips, n_chunks;   // wave grid, in units (a wave, or the workgroup of a staged sweep)
+    // The last units of the grid (dispatched last) take shorter chunks, so that the ragged end of a
     // launch -- SIMDs left with one or two waves -- is short.  Tier t covers chunks
     // [tier_first[t], tier_first[t+1]) with tier_rows[t] rows each; tier 0 starts at out_begin.
     static constexpr int max_tiers = 4;
@@ -394,53 +404,11 @@ struct SweepGeometry {
     std::uint32_t tier_first[max_tiers + 1];
     std::int32_t tier_rows[max_tiers];
     std::int32_t tier_begin[max_tiers]; // first output row of the tier
-    std::uint64_t pitch;                // elements between rows
-    std::uint32_t pitch32;              // the same (below 2^31, checked at launch)
+    std::uint32_t pitch32;              // elements between rows (below 2^31, checked at launch)
     std::uint64_t iteration;            // generation index of the first level
     std::uint32_t xcd_remap;            // 1: give every XCD a contiguous range of the wave grid
     std::uint32_t last_chunk_early;     // 1: the last row chunk is dispatched second instead of last
-    // Persistent waves (sweep_kernel<..., PERSISTENT>): the rows are cut into fine chunks of `fine_rows`; a wave
-    // claims a chunk, and when it has finished it claims the chunk BELOW and keeps streaming -- its pipeline holds
-    // exactly the state that chunk needs, so only the first chunk of a run pays the 2G warm-up rows -- until it
-    // meets a chunk somebody else has claimed; then it takes the next unclaimed chunk from a shared cursor.
-    std::uint32_t fine_rows, n_fine;    // rows per fine chunk, chunks per strip
-    std::uint32_t starts_per_strip;     // runs that start side by side in one strip (cursor phase 0)
-    std::uint32_t start_stride;         // distance of those starts in chunks
-    std::uint32_t phase_step;           // chunks between the starts of consecutive ticket phases
-    std::uint32_t cursor_end;           // tickets: phases * starts_per_strip * n_strips
-    std::uint32_t *claims;              // one word per (chunk, strip), zeroed before the launch
-    std::uint32_t *cursor;              // one word, zeroed before the launch
 };
-
-template <typename F, bool SOA> constexpr bool cooperative_for() {
-    if constexpr (requires { SweepTuning<F, SOA>::cooperative; })
-        return SweepTuning<F, SOA>::cooperative;
-    else
-        return false;
-}
-
-// SweepTuning<F, SOA>::persistent (optional member, default false): launch as many waves as stay resident and let
-// each claim fine row chunks, continuing into the chunk below without re-warming its pipeline (SweepGeometry).
-template <typename F, bool SOA> constexpr bool persistent_for() {
-    if constexpr (requires { SweepTuning<F, SOA>::persistent; })
-        return SweepTuning<F, SOA>::persistent;
-    else
-        return false;
-}
-
-template <typename F, bool SOA> constexpr int cooperative_debug_for() {
-    if constexpr (requires { SweepTuning<F, SOA>::cooperative_debug; })
-        return SweepTuning<F, SOA>::cooperative_debug;
-    else
-        return 0;
-}
-
-template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
-    if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })
-        return SweepTuning<F, SOA>::trapezoid_fill;
-    else
-        return cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 4;
-}
 
 // A transition function may declare fields it only copies from the centre cell,
 //     static constexpr auto constant_fields = std::make_tuple(&Cell::power);
@@ -466,24 +434,18 @@ template <typename F> constexpr std::uint32_t constant_plane_mask() {
     return mask;
 }
 
-// Non-temporal stores of the results (SweepTuning<F, SOA>::streaming_stores, optional member).  Measured
-// (profiles/r01_ab_nt_stores.txt): +1.2..1.6 % Jacobi, +1..5 % HotSpot fp32, +2..4 % HotSpot fp64 on planes; but
-// -8 % FDTD on planes, -1 % FDTD / HotSpot fp64 as AoS and -3 % for the packed Game of Life -- the kernels that are
-// bound by HBM or store narrow rows pay for partial lines that L2 no longer merges.  Default: cells of up to two
-// 32-bit words per generation that are at least one word wide.
-template <typename F, bool SOA> constexpr bool streaming_stores_for() {
-    if constexpr (requires { SweepTuning<F, SOA>::streaming_stores; })
-        return SweepTuning<F, SOA>::streaming_stores;
-    else
-        return sizeof(typename F::Cell) >= 4 &&
-               cell_words<typename F::Cell, SOA>() * int(F::n_subiterations) <= 2;
+// Independent waves (stages = 1): 4 waves per workgroup, 2 or 1 are 1-3 % slower (profiles/r01_tune_taper.txt).
+constexpr int independent_waves_per_block = 4;
+
+// Largest divisor of `levels` that is at most `wanted`: the stage count a launch of `levels` levels runs with.
+constexpr int stages_dividing(int levels, int wanted) {
+    int w = wanted < 1 ? 1 : wanted;
+    while (levels % w != 0)
+        w--;
+    return w;
 }
 
-constexpr int waves_per_block = 4; // 4 waves per workgroup: 2 or 1 are 1-3 % slower (profiles/r01_tune_taper.txt)
-
-// COOP_DEBUG (timing experiments only, results are wrong): 1 = no barrier, 2 = no LDS traffic, 3 = neither
-template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT, bool COOP = false, int COOP_DEBUG = 0,
-          bool INLINE_TDV = false>
+template <typename F, bool SOA, int T, int K, int P, bool INTERIOR_VARIANT, int STAGES = 1, bool INLINE_TDV = false>
 struct Sweep {
     using Cell = typename F::Cell;
     using TDV = typename F::TimeDependentValue;
@@ -496,101 +458,99 @@ struct Sweep {
     static constexpr int G = R * S;             // halo depth in cells (rows and columns)
     static constexpr int GX = round_up(G, K);   // column halo rounded to whole lanes
     static constexpr int LW = wave_size * K;    // columns a wave loads
-    // columns one unit of the wave grid loads / produces: a wave, or (COOP) the waves of a workgroup
-    static constexpr int UW = COOP ? waves_per_block * LW : LW;
-    static constexpr int OW = UW - 2 * GX;
-    static constexpr int OW_PER_WAVE = COOP ? OW / waves_per_block : OW; // what the launch heuristics count waves with
+    static constexpr int OW = LW - 2 * GX;      // columns a unit of the wave grid produces
     static constexpr int NWIN = 2 * R;          // rows each level keeps
     static constexpr int D = 2 * R + 1;
     static constexpr int prefetch_depth = P;
 
-    // COOP: edge columns in LDS.  Slot (step mod N_SLOTS) holds, per level and wave, the R westernmost cells of
-    // lane 0 and the R easternmost cells of lane 63 of the row that entered that level's window in that step.
-    static constexpr int CW = int((sizeof(Cell) + 3) / 4);          // 32-bit words per cell
-    static constexpr int N_SLOTS = 2 * R + 1;                       // rows alive in a window + the one being written
-    static constexpr int EDGE_WORDS = R * CW;                       // one edge of one wave at one level
-    static constexpr int LEVEL_WORDS = waves_per_block * 2 * EDGE_WORDS;
-    static constexpr int SLOT_WORDS = S * LEVEL_WORDS;
-    static constexpr int LDS_WORDS = COOP ? N_SLOTS * SLOT_WORDS : 1;
+    // Staged sweep: the W waves of a workgroup share one column strip.  Stage s keeps the windows of its own L levels
+    // only, takes its input rows from stage s-1 and passes its output rows to stage s+1 through LDS, in batches of P
+    // rows: interface i (between stages i and i+1) is a ring of two batches, one workgroup barrier per batch.  Stage
+    // s works on batch b during super-step b + s, so a batch written in one super-step is read in the next.
+    static constexpr int W = stages_dividing(S, STAGES);
+    static constexpr int L = S / W;             // levels per stage
+    static constexpr int block_waves = W > 1 ? W : independent_waves_per_block;
+    static constexpr int units_per_block = W > 1 ? 1 : independent_waves_per_block;
+    // what the launch heuristics count waves with: columns produced per wave
+    static constexpr int OW_PER_WAVE = W > 1 ? (OW / W > 0 ? OW / W : 1) : OW;
+    static constexpr int CW = int((sizeof(Cell) + 3) / 4);  // 32-bit words per cell in LDS
+    static constexpr int LANE_WORDS = K * CW;               // one lane's cells of one row
+    static constexpr int ROW_WORDS = wave_size * LANE_WORDS;
+    static constexpr int IFACE_WORDS = 2 * P * ROW_WORDS;   // two batches of P rows
+    static constexpr int LDS_WORDS = W > 1 ? (W - 1) * IFACE_WORDS : 1;
+    static constexpr int lane_align = (LANE_WORDS % 4 == 0) ? 16 : ((LANE_WORDS % 2 == 0) ? 8 : 4);
 
     static_assert(K >= R, "a lane must hold at least `radius` cells so neighbours are one lane away");
     static_assert(OW >= K, "halo consumes the whole strip: lower max_generations or raise K");
-    static_assert(!COOP || LDS_WORDS * 4 <= 64 * 1024, "edge exchange buffers exceed the LDS budget of a workgroup");
+    static_assert(LDS_WORDS * 4 <= 64 * 1024, "the row rings of a staged sweep exceed the LDS budget of a workgroup");
     static_assert(P % NWIN == 0, "prefetch depth must be a multiple of the window length");
     static_assert(std::is_trivially_copyable_v<F> && std::is_trivially_copyable_v<Cell> &&
                   std::is_trivially_copyable_v<TDV>);
 
     struct Args {
-        F f;
-        Cell halo;
         // Time-dependent values of the launch's T generations, one of three sources (tdv/SinglePassStrategies.hpp):
         // `tdv_table` != nullptr: device array, element i = generation i of this launch (the pass driver's per-call
         // table: precomputed on the host or on the device); else `tdv`: evaluated on the host for this launch
-        // and shipped as kernel arguments; INLINE_TDV: evaluated by the kernel itself, neither is read.
+        // and shipped as kernel arguments (FIRST member: the kernel reads them at offset 0 of its argument
+        // segment); INLINE_TDV: evaluated by the kernel itself, neither is read.
         TDV tdv[T];
         TDV const *tdv_table;
+        F f;
+        Cell halo;
         Planes src, dst;
         SweepGeometry geo;
     };
 
+    struct alignas(lane_align) LanePacket {
+        std::uint32_t w[LANE_WORDS];
+    };
+    STST_DEVICE static void lds_store_row(std::uint32_t *lds, int iface, int slot, int lane, Cell const (&cells)[K]) {
+        LanePacket packet = {};
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            __builtin_memcpy(&packet.w[k * CW], &cells[k], sizeof(Cell));
+        *reinterpret_cast<LanePacket *>(lds + iface * IFACE_WORDS + slot * ROW_WORDS + lane * LANE_WORDS) = packet;
+    }
+    STST_DEVICE static void lds_load_row(const std::uint32_t *lds, int iface, int slot, int lane, Cell (&cells)[K]) {
+        const LanePacket packet =
+            *reinterpret_cast<const LanePacket *>(lds + iface * IFACE_WORDS + slot * ROW_WORDS + lane * LANE_WORDS);
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            __builtin_memcpy(&cells[k], &packet.w[k * CW], sizeof(Cell));
+    }
+
+    // One wave = stage SG of the unit (strip, rows [ya, yb)).
     // SKIP_CONSTANTS: the target planes of F::constant_fields already hold their values (see
     // constant_plane_mask); their stores are left out
-    // `strip`: index of the unit (wave, or workgroup if COOP) along the columns; `wib`: wave in the workgroup
-    // `more_rows(yb)`: persistent waves only -- called when the rows up to yb are done, returns the new end of the
-    // wave's rows if it could claim the chunk below (then the wave keeps streaming), or yb.
-    // Returns the row the wave's output ends at.
-    template <bool EDGE, bool SKIP_CONSTANTS, typename MoreRows>
-    STST_DEVICE static int run(Args const &a, const int lane, const int strip, const int ya,
-                               const int yb_first, const int wib, std::uint32_t *lds, MoreRows more_rows) {
-        constexpr bool CONTINUES = !std::is_same_v<MoreRows, std::nullptr_t>;
-        int yb = yb_first;
+    template <bool EDGE, bool SKIP_CONSTANTS, int SG>
+    STST_DEVICE static void run(Args const &a, const int lane, const int strip, const int ya, const int yb,
+                                std::uint32_t *lds) {
         constexpr std::uint32_t skip_mask = SKIP_CONSTANTS ? constant_plane_mask<F>() : 0u;
+        constexpr int L0 = SG * L; // levels below this stage
         SweepGeometry const &g = a.geo;
-        const int unit_x = COOP ? wib * LW + lane * K : lane * K; // column of the lane inside its unit
-        const int x0 = strip * OW - GX + unit_x; // global column of the lane's first cell
+        const int x0 = strip * OW - GX + lane * K; // global column of the lane's first cell
         const int ystart = ya - G;
-        // a wave that may continue below its chunk prefetches real rows there: up to what the launch may read
-        const int y_load_end = CONTINUES ? (g.out_end + G < g.load_hi ? g.out_end + G : g.load_hi)
-                                         : (yb + G < g.load_hi ? yb + G : g.load_hi);
+        const int y_load_end = yb + G < g.load_hi ? yb + G : g.load_hi;
 
         bool col_in[K];
 #pragma unroll
         for (int k = 0; k < K; k++)
             col_in[k] = unsigned(x0 + k) < unsigned(g.grid_w);
         const bool vec_in = x0 >= 0 && x0 + K <= g.grid_w;
-        const bool lane_stores = unit_x >= GX && unit_x + K <= UW - GX;
+        const bool lane_stores = lane * K >= GX && lane * K + K <= LW - GX;
 
-        // COOP: LDS word offsets.  A lane reads the neighbour waves' edges (every lane the same address; only the
-        // value of lane 0 / 63 is used) and the two edge lanes write their own.
-        int lds_west = 0, lds_east = 0, lds_mine = 0; // words inside a (slot, level) block
-        if constexpr (COOP) {
-            const int w_west = wib > 0 ? wib - 1 : 0, w_east = wib + 1 < waves_per_block ? wib + 1 : wib;
-            lds_west = (w_west * 2 + 1) * EDGE_WORDS; // east edge of the wave to the west
-            lds_east = (w_east * 2 + 0) * EDGE_WORDS; // west edge of the wave to the east
-            lds_mine = (wib * 2 + (lane == 0 ? 0 : 1)) * EDGE_WORDS;
-        }
-        int slot_now = 0; // slot written in this step; the row of m steps ago is in slot (slot_now - m) mod N_SLOTS
-        auto lds_cell = [&](int slot, int level_index, int edge_offset, int e) __attribute__((always_inline)) {
-            Cell cell;
-            std::uint32_t words[CW] = {};
-            const std::uint32_t *from = lds + slot * SLOT_WORDS + level_index * LEVEL_WORDS + edge_offset + e * CW;
-#pragma unroll
-            for (int i = 0; i < CW; i++)
-                words[i] = from[i];
-            __builtin_memcpy(&cell, words, sizeof(Cell));
-            return cell;
-        };
-
-        // The launch's time-dependent values: the call's device table, or the kernel arguments.  Both are read
-        // through the constant address space -- nothing writes them while the kernel runs --, so the compiler may
-        // load a value again wherever it needs it instead of holding T scalar registers over the row loop (a plain
-        // global load could not be moved over the loop's stores at all).
+        // The launch's time-dependent values: the call's device table, or the kernel arguments (Args::tdv sits at
+        // offset 0 of the kernel's argument segment).  Both are read through the constant address space -- nothing
+        // writes them while the kernel runs --, so the compiler may load a value again wherever it needs it instead
+        // of holding T scalar registers over the row loop (a plain global load could not be moved over the loop's
+        // stores at all).
         using ConstantTDV = const TDV __attribute__((address_space(4)));
-        ConstantTDV *launch_tdv = a.tdv_table ? (ConstantTDV *)(a.tdv_table) : (ConstantTDV *)(a.tdv);
+        ConstantTDV *launch_tdv = a.tdv_table ? (ConstantTDV *)(a.tdv_table)
+                                              : (ConstantTDV *)(__builtin_amdgcn_kernarg_segment_ptr());
 
-        Cell win[S][NWIN][K]; // level l-1's older rows, rotating
-        Cell pre[P][K];       // rows in flight from HBM
-        static_for<0, S>([&](auto l) __attribute__((always_inline)) {
+        Cell win[L][NWIN][K]; // level l-1's older rows, rotating
+        Cell pre[P][K];       // rows in flight from HBM (stage 0) or fetched from the LDS ring
+        static_for<0, L>([&](auto l) __attribute__((always_inline)) {
             static_for<0, NWIN>([&](auto s) __attribute__((always_inline)) {
 #pragma unroll
                 for (int k = 0; k < K; k++)
@@ -626,54 +586,35 @@ struct Sweep {
             }
         };
 
-        static_for<0, P>([&](auto u) __attribute__((always_inline)) { load_row(ystart + u, pre[u]); });
+        if constexpr (SG == 0)
+            static_for<0, P>([&](auto u) __attribute__((always_inline)) { load_row(ystart + u, pre[u]); });
 
-        // One input row through the pipeline.  While the pipeline fills (FILLING: the first 2G rows of the
-        // wave) level l only has to produce rows from input row 2*l*R of the wave on -- earlier outputs
-        // cannot reach a stored row -- so the deeper levels are skipped by wave-uniform branches: a
-        // trapezoid of level-steps instead of a parallelogram, G*(S+1) fewer of them per wave.
-        int n_rows_in = yb - ya + 2 * G;
-        auto row_step = [&](auto u, const int it, auto filling) __attribute__((always_inline)) {
+        // One input row through this stage's levels.  `step` counts the rows fed to level 1 of the unit; the row this
+        // stage receives at `step` is what level L0 emitted for it.  While the pipeline fills (FILLING) level l only
+        // has to produce rows from step 2*l*R on -- earlier outputs cannot reach a stored row -- so the deeper levels
+        // are skipped by wave-uniform branches: a trapezoid of level-steps instead of a parallelogram.
+        auto row_step = [&](auto u, const int it, auto filling, const int ring) __attribute__((always_inline)) {
                 constexpr bool FILLING = decltype(filling)::value;
-                const int step = it + u; // index of the input row inside the wave
-                const int y = ystart + it + u;
+                const int step = it + u;
+                const int y = ystart + step; // global row entering level 1 at this step
                 Cell cur[K];
 #pragma unroll
                 for (int k = 0; k < K; k++)
                     cur[k] = pre[u][k];
-                load_row(y + P, pre[u]);
-
-                if constexpr (EDGE) {
-                    const bool row_in = unsigned(y) < unsigned(g.grid_h);
+                if constexpr (SG == 0) {
+                    load_row(y + P, pre[u]);
+                    if constexpr (EDGE) {
+                        const bool row_in = unsigned(y) < unsigned(g.grid_h);
 #pragma unroll
-                    for (int k = 0; k < K; k++)
-                        if (!(row_in && col_in[k]))
-                            cur[k] = a.halo;
-                }
-
-                // COOP: the neighbour waves' edge cells of the window rows of every level, fetched before this
-                // step writes anything to LDS (so the reads are not ordered behind those writes and their
-                // latency is paid once per row, not once per level); what the transition function does not
-                // use is never loaded.  Window row rr entered D-1-rr steps ago and has crossed a barrier since.
-                Cell edge_west[COOP ? S : 1][D - 1][R], edge_east[COOP ? S : 1][D - 1][R];
-                if constexpr (COOP && !(COOP_DEBUG & 2)) {
-                    static_for<0, S>([&](auto lc) __attribute__((always_inline)) {
-                        static_for<0, D - 1>([&](auto rr) __attribute__((always_inline)) {
-                            constexpr int age = D - 1 - int(rr);
-                            int slot = slot_now - age;
-                            slot = slot < 0 ? slot + N_SLOTS : slot;
-#pragma unroll
-                            for (int e = 0; e < R; e++) {
-                                edge_west[lc][rr][e] = lds_cell(slot, lc, lds_west, e);
-                                edge_east[lc][rr][e] = lds_cell(slot, lc, lds_east, e);
-                            }
-                        });
-                    });
+                        for (int k = 0; k < K; k++)
+                            if (!(row_in && col_in[k]))
+                                cur[k] = a.halo;
+                    }
                 }
 
                 bool live = true; // FILLING: the levels up to here are due at this row
-                static_for<0, S>([&](auto lc) __attribute__((always_inline)) {
-                    constexpr int level = lc + 1;           // level being computed
+                static_for<0, L>([&](auto lc) __attribute__((always_inline)) {
+                    constexpr int level = L0 + lc + 1;      // level being computed, 1 .. S
                     constexpr int oldest = u % NWIN;        // window slot holding the oldest row
                     if constexpr (FILLING) {
                         if (!live)
@@ -711,18 +652,10 @@ struct Sweep {
 #pragma unroll
                         for (int k = 0; k < K; k++)
                             ext[rr][R + k] = row[k];
-                        if constexpr (COOP && !(COOP_DEBUG & 2) && rr < D - 1) {
 #pragma unroll
-                            for (int d = 1; d <= R; d++) {
-                                ext[rr][R - d] = from_west_lane_or(row[K - d], edge_west[lc][rr][R - d]);
-                                ext[rr][R + K - 1 + d] = from_east_lane_or(row[d - 1], edge_east[lc][rr][d - 1]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int d = 1; d <= R; d++) {
-                                ext[rr][R - d] = from_west_lane(row[K - d]);
-                                ext[rr][R + K - 1 + d] = from_east_lane(row[d - 1]);
-                            }
+                        for (int d = 1; d <= R; d++) {
+                            ext[rr][R - d] = from_west_lane(row[K - d]);
+                            ext[rr][R + K - 1 + d] = from_east_lane(row[d - 1]);
                         }
                     });
 
@@ -754,7 +687,7 @@ struct Sweep {
                         // a transition function may provide a form that knows its level inside the
                         // launch at compile time (used by fused forms whose first / last level differ)
                         if constexpr (requires { a.f.template at_level<0, 1>(st); })
-                            next[k] = a.f.template at_level<decltype(lc)::value, S>(st);
+                            next[k] = a.f.template at_level<level - 1, S>(st);
                         // ... or a form for cells that are not on the rim of the grid: in a wave whose
                         // whole footprint lies inside the grid every cell that can reach the output has
                         // 0 < row < height-1 and 0 < column < width-1 at every level
@@ -775,72 +708,69 @@ struct Sweep {
                     }
                 });
 
-                const int j = y - G; // row leaving the last level
-                if ((!FILLING || live) && j >= ya && j < yb && lane_stores) {
-                    const std::size_t first =
-                        row_offset(g, j) + std::size_t(std::int64_t(x0));
-                    if (!EDGE || vec_in) {
-                        a.dst.template store<K, streaming_stores_for<F, SOA>(), skip_mask>(first, cur);
-                    } else {
+                if constexpr (SG == W - 1) {
+                    const int j = y - G; // row leaving the last level
+                    if ((!FILLING || live) && j >= ya && j < yb && lane_stores) {
+                        const std::size_t first =
+                            row_offset(g, j) + std::size_t(std::int64_t(x0));
+                        if (!EDGE || vec_in) {
+                            a.dst.template store<K, streaming_stores_for<F, SOA>(), skip_mask>(first, cur);
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < K; k++)
-                            if (col_in[k])
-                                a.dst.template store_one<skip_mask>(first + k, cur[k]);
+                            for (int k = 0; k < K; k++)
+                                if (col_in[k])
+                                    a.dst.template store_one<skip_mask>(first + k, cur[k]);
+                        }
                     }
-                }
-                if constexpr (COOP) {
-                    // The rows that entered the windows in this step now sit in the windows' `oldest` slots (they
-                    // replaced the oldest rows): their edge cells go to the neighbour waves.  One masked block per
-                    // step -- a branch per level would cut the step into basic blocks too small for the scheduler
-                    // to interleave the levels.
-                    if ((lane == 0 || lane == wave_size - 1) && !(COOP_DEBUG & 2)) {
-                        static_for<0, S>([&](auto lc) __attribute__((always_inline)) {
-                            constexpr int entered = u % NWIN;
-                            std::uint32_t *to = lds + slot_now * SLOT_WORDS + lc * LEVEL_WORDS + lds_mine;
-#pragma unroll
-                            for (int e = 0; e < R; e++) {
-                                Cell const &cell = lane == 0 ? win[lc][entered][e] : win[lc][entered][K - R + e];
-                                std::uint32_t words[CW] = {};
-                                __builtin_memcpy(words, &cell, sizeof(Cell));
-#pragma unroll
-                                for (int i = 0; i < CW; i++)
-                                    to[e * CW + i] = words[i];
-                            }
-                        });
-                    }
-                    // edges of this step become visible to the other waves; LDS only -- the rows in flight from
-                    // HBM (pre[]) must not be waited for here
-                    if constexpr (!(COOP_DEBUG & 1)) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                        __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                    }
-                    slot_now = slot_now + 1 == N_SLOTS ? 0 : slot_now + 1;
+                } else {
+                    // the row this stage emits: input of the next stage, one super-step later
+                    if (!FILLING || live)
+                        lds_store_row(lds, SG, ring + u, lane, cur);
                 }
         };
 
-        // Waves at the grid edge are few: they keep one loop (every level at every row) and small code.
-        int it = 0;
-        if constexpr (!EDGE && trapezoid_fill_for<F, SOA>()) {
-            for (; it < 2 * G && it < n_rows_in; it += P)
-                static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, it, std::true_type{}); });
-        }
-        for (; it < n_rows_in; it += P)
-            static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, it, std::false_type{}); });
-        if constexpr (CONTINUES) {
-            // exactly n_rows_in rows have been fed (the launcher keeps chunk lengths and 2G multiples of P): the
-            // pipeline is in the state the chunk below starts from
-            while (it == n_rows_in) {
-                const int further = more_rows(yb);
-                if (further == yb)
-                    break;
-                yb = further;
-                n_rows_in = yb - ya + 2 * G;
-                for (; it < n_rows_in; it += P)
-                    static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, it, std::false_type{}); });
+        // Super-step t: stage SG works on batch t - SG (rows [b*P, (b+1)*P) of the unit's feed).  Every wave of the
+        // workgroup passes the same number of barriers, whether it has a batch in this super-step or not.
+        constexpr bool TRAPEZOID = !EDGE && trapezoid_fill_for<F, SOA>();
+        // batches before this one hold nothing this stage needs: its first level is due from step 2*(L0+1)*R on and
+        // reads window rows from 2R steps before that
+        constexpr int first_batch = TRAPEZOID ? (2 * L0 * R) / P : 0;
+        const int n_rows_in = yb - ya + 2 * G;
+        const int n_batches = (n_rows_in + P - 1) / P;
+        const int n_super = n_batches + (W - 1);
+        auto super_step = [&](const int t, auto filling) __attribute__((always_inline)) {
+            if constexpr (W > 1) {
+                // rows of the previous super-step become visible to the next stage; LDS only -- the rows in flight
+                // from HBM (pre[]) must not be waited for here
+                // (the explicit wait is not redundant: the compiler may leave out the wait a release fence implies when it
+                // has seen an earlier wait of its own, and a row then reaches the next stage late -- measured: one wrong
+                // launch in a few hundred with the fences alone)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             }
+            const int b = t - SG;
+            if (b < first_batch || b >= n_batches)
+                return;
+            const int ring = (b & 1) * P;
+            if constexpr (SG > 0)
+                static_for<0, P>([&](auto u) __attribute__((always_inline)) {
+                    lds_load_row(lds, SG - 1, ring + u, lane, pre[u]);
+                });
+            static_for<0, P>([&](auto u) __attribute__((always_inline)) { row_step(u, b * P, filling, ring); });
+        };
+        int t = 0;
+        if constexpr (TRAPEZOID) {
+            // super-steps in which some level of this stage is not due yet
+            constexpr int fill_batches = (2 * (L0 + L) * R + P - 1) / P;
+            const int t_fill = SG + fill_batches < n_super ? SG + fill_batches : n_super;
+            for (; t < t_fill; t++)
+                super_step(t, std::true_type{});
         }
-        return yb;
+        for (; t < n_super; t++)
+            super_step(t, std::false_type{});
     }
 
     template <bool SKIP_CONSTANTS = false> STST_DEVICE static void entry(Args const &a, std::uint32_t *lds) {
@@ -857,9 +787,10 @@ struct Sweep {
             const unsigned q = gridDim.x / n_xcd, r = gridDim.x % n_xcd, x = block % n_xcd;
             block = x * q + (x < r ? x : r) + block / n_xcd;
         }
-        // unit of the wave grid: a wave, or (COOP) the whole workgroup -- its waves then share strip and chunk,
-        // run the same number of rows and meet at one barrier per row
-        const unsigned unit = COOP ? block : __builtin_amdgcn_readfirstlane(block * unsigned(waves_per_block) + unsigned(wib));
+        // unit of the wave grid: a wave, or (staged) the whole workgroup -- its waves then share strip and chunk,
+        // run the same number of super-steps and meet at one barrier per batch of rows
+        const unsigned unit = W > 1 ? block
+                                    : __builtin_amdgcn_readfirstlane(block * unsigned(units_per_block) + unsigned(wib));
         if (unit >= g.n_strips * g.n_chunks)
             return;
         const int strip = int(unit % g.n_strips);
@@ -877,17 +808,23 @@ struct Sweep {
         int yb = ya + g.tier_rows[tier];
         yb = yb < g.out_end ? yb : g.out_end;
 
-        if constexpr (INTERIOR_VARIANT) {
-            const int xw0 = strip * OW - GX; // footprint of the unit: decided per workgroup when COOP
-            const bool interior =
-                xw0 >= 0 && xw0 + UW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
-            if (interior)
-                run<false, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, nullptr);
-            else
-                run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, nullptr);
-        } else {
-            run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, nullptr);
-        }
+        const int xw0 = strip * OW - GX; // footprint of the unit
+        const bool interior =
+            INTERIOR_VARIANT && xw0 >= 0 && xw0 + LW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
+        // the stage of a wave is a compile-time property of the code it runs (levels, iteration and sub-iteration
+        // indices, fused forms): one instantiation per stage, selected by the wave's index in the workgroup
+        static_for<0, W>([&](auto sg) __attribute__((always_inline)) {
+            if (W > 1 && wib != int(sg))
+                return;
+            if constexpr (INTERIOR_VARIANT) {
+                if (interior)
+                    run<false, SKIP_CONSTANTS, int(sg)>(a, lane, strip, ya, yb, lds);
+                else
+                    run<true, SKIP_CONSTANTS, int(sg)>(a, lane, strip, ya, yb, lds);
+            } else {
+                run<true, SKIP_CONSTANTS, int(sg)>(a, lane, strip, ya, yb, lds);
+            }
+        });
     }
 
     // Element offset of buffer row `y` (a global row the buffers hold): both factors fit 31 bits (checked at launch),
@@ -896,123 +833,52 @@ struct Sweep {
     STST_DEVICE static std::size_t row_offset(SweepGeometry const &g, int y) {
         return std::size_t(std::uint32_t(y - g.row_origin)) * std::size_t(g.pitch32);
     }
-
-    // ---- persistent waves (see SweepGeometry) ----
-    static constexpr bool can_continue = !COOP && (2 * G) % P == 0;
-
-    STST_DEVICE static bool claim(SweepGeometry const &g, std::uint32_t item, int lane) {
-        std::uint32_t got = 0;
-        if (lane == 0)
-            got = atomicCAS(g.claims + item, 0u, 1u) == 0u ? 1u : 0u;
-        return __builtin_amdgcn_readfirstlane(got) != 0;
-    }
-    STST_DEVICE static bool chunk_is_interior(SweepGeometry const &g, int strip, int ya, int yb) {
-        const int xw0 = strip * OW - GX;
-        return INTERIOR_VARIANT && xw0 >= 0 && xw0 + UW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
-    }
-
-    template <bool SKIP_CONSTANTS = false> STST_DEVICE static void entry_persistent(Args const &a, std::uint32_t *lds) {
-        SweepGeometry const &g = a.geo;
-        const int lane = int(threadIdx.x) & (wave_size - 1);
-        const int wib = int(__builtin_amdgcn_readfirstlane(threadIdx.x / wave_size));
-        // One ticket per wave, in dispatch order.  The first starts_per_strip * n_strips tickets (one residency
-        // round) start runs evenly spaced in every strip; a run goes down its strip chunk by chunk until the chunk
-        // below belongs to somebody else -- who by the same rule takes care of everything below it -- so every chunk
-        // is swept exactly once.  The later tickets (phases 1, 2, ...) point at chunks inside those runs' ranges:
-        // their waves only start when a slot frees up, find their chunk taken if the run above has got there (then
-        // they end at once), and otherwise split what a slow or late run has left.  No wave waits for another.
-        const std::uint32_t ticket = __builtin_amdgcn_readfirstlane(blockIdx.x * std::uint32_t(waves_per_block) + std::uint32_t(wib));
-        if (ticket >= g.cursor_end)
-            return;
-        const std::uint32_t per_phase = g.starts_per_strip * g.n_strips;
-        const std::uint32_t phase = ticket / per_phase, rest = ticket % per_phase;
-        const int strip = int(rest % g.n_strips);
-        std::uint32_t chunk = (rest / g.n_strips) * g.start_stride + phase * g.phase_step;
-        if (chunk >= g.n_fine || !claim(g, chunk * g.n_strips + std::uint32_t(strip), lane))
-            return;
-        for (;;) {
-            const int ya = g.out_begin + int(chunk * g.fine_rows);
-            int yb = ya + int(g.fine_rows);
-            yb = yb < g.out_end ? yb : g.out_end;
-            const bool interior = chunk_is_interior(g, strip, ya, yb);
-            // the chunk below, if it is free and runs the same code path (interior / edge): keep streaming
-            auto more_rows = [&](int done_to) __attribute__((always_inline)) -> int {
-                if (done_to >= g.out_end)
-                    return done_to;
-                const std::uint32_t next = std::uint32_t(done_to - g.out_begin) / g.fine_rows;
-                int next_end = done_to + int(g.fine_rows);
-                next_end = next_end < g.out_end ? next_end : g.out_end;
-                if (chunk_is_interior(g, strip, done_to, next_end) != interior)
-                    return done_to;
-                return claim(g, next * g.n_strips + std::uint32_t(strip), lane) ? next_end : done_to;
-            };
-            int done_to;
-            if constexpr (INTERIOR_VARIANT) {
-                if (interior)
-                    done_to = run<false, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, more_rows);
-                else
-                    done_to = run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, more_rows);
-            } else {
-                done_to = run<true, SKIP_CONSTANTS>(a, lane, strip, ya, yb, wib, lds, more_rows);
-            }
-            // the code path changes at the chunk below (or the feed did not end on a chunk boundary): a fresh run
-            if (done_to >= g.out_end)
-                return;
-            chunk = std::uint32_t(done_to - g.out_begin) / g.fine_rows;
-            if (!claim(g, chunk * g.n_strips + std::uint32_t(strip), lane))
-                return;
-        }
-    }
 };
 
 // The sweep SweepTuning<F, SOA> asks for, at blocking depth T.
 template <typename F, bool SOA, int T = SweepTuning<F, SOA>::max_generations, bool INLINE_TDV = false>
 using SweepOf = Sweep<F, SOA, T, SweepTuning<F, SOA>::cells_per_lane, SweepTuning<F, SOA>::prefetch_rows,
-                      SweepTuning<F, SOA>::interior_variant, cooperative_for<F, SOA>(), cooperative_debug_for<F, SOA>(),
-                      INLINE_TDV>;
+                      SweepTuning<F, SOA>::interior_variant, stages_for<F, SOA>(), INLINE_TDV>;
 
 // MIN_WAVES = waves per SIMD the register allocator must leave room for (launch-bounds semantics).
-template <typename SW, int MIN_WAVES = 1, bool SKIP_CONSTANTS = false, bool PERSISTENT = false>
-__global__ void __launch_bounds__(256, MIN_WAVES) sweep_kernel(const typename SW::Args args) {
-    __shared__ std::uint32_t edge_columns[SW::LDS_WORDS]; // cooperative strips only (one word otherwise)
-    if constexpr (PERSISTENT)
-        SW::template entry_persistent<SKIP_CONSTANTS>(args, edge_columns);
-    else
-        SW::template entry<SKIP_CONSTANTS>(args, edge_columns);
+template <typename SW, int MIN_WAVES = 1, bool SKIP_CONSTANTS = false>
+__global__ void __launch_bounds__(SW::block_waves * wave_size, MIN_WAVES) sweep_kernel(const typename SW::Args args) {
+    // the row rings between the stages of a staged sweep (one word otherwise)
+    __shared__ __attribute__((aligned(16))) std::uint32_t rings[SW::LDS_WORDS];
+    SW::template entry<SKIP_CONSTANTS>(args, rings);
 }
 
 // ------------------------------------------------------------------ host side
-inline int env_int(const char *name, int fallback) {
-    const char *v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : fallback;
-}
+// Tuning knobs come from the environment ONCE (ststhip_options: read at ststhip_init, again on
+// ststhip_reload_options), not per launch.
+inline ststhip_options const &options() { return *ststhip_get_options(); }
 
-// Rows of output per wave.  A wave costs (rows + 2*G warm-up rows + prologue); the chip keeps
-// S = CUs * resident workgroups * 4 waves in flight and back-fills as waves retire, so
-//   time ~ waves * cost / S  +  alpha * cost      (alpha ~ 0.5: the ragged tail of the last waves)
-// with waves = strips * out_rows / rows.  Minimising over rows gives the closed form below: long
+// Rows of output per unit of the wave grid.  A unit costs (rows + 2*G warm-up rows + prologue); the chip keeps
+// `slots` units in flight and back-fills as they retire, so
+//   time ~ units * cost / slots  +  alpha * cost      (alpha ~ 0.5: the ragged tail of the last units)
+// with units = strips * out_rows / rows.  Minimising over rows gives the closed form below: long
 // chunks waste the tail, short chunks waste warm-up rows.  (Measured optimum for Jacobi 16384^2,
 // T = 8: ~135 rows; the formula gives 133.)
-inline int pick_chunk_rows(int out_rows, unsigned n_strips, int halo_rows, int resident_blocks,
-                           int waves_per_block) {
-    int forced = env_int("STSTHIP_CHUNK_ROWS", 0);
-    if (forced > 0)
-        return std::min(forced, std::max(out_rows, 1));
+inline int pick_chunk_rows(int out_rows, unsigned n_strips, int overhead_rows, int resident_blocks,
+                           int units_per_block) {
+    ststhip_options const &opt = options();
+    if (opt.chunk_rows > 0)
+        return std::min(opt.chunk_rows, std::max(out_rows, 1));
     int cus = 256;
     ststhip_compute_units(&cus);
     // launches running side by side (row strips of the pass driver) fill each other's tails: the tail
     // weight shrinks by their number (fitted to chunk sweeps of Jacobi 16384^2 and HotSpot 8192^2)
     const int side_by_side = std::max(1, ststhip_launch_concurrency());
-    const double slots = double(cus) * std::max(resident_blocks, 1) * waves_per_block;
+    const double slots = double(cus) * std::max(resident_blocks, 1) * units_per_block;
     // tail weight: 0.5 for a launch that has the chip to itself; launches that run side by side (their boundary
     // bands on streams of their own) want slightly longer chunks still (profiles/r02_ab_bands_beside.txt)
-    const double alpha = env_int("STSTHIP_TAIL_PERMILLE", side_by_side > 1 ? 350 : 500) / 1000.0 / side_by_side;
-    const double overhead = 2.0 * halo_rows + 8.0;
+    const double alpha = (opt.tail_permille > 0 ? opt.tail_permille : (side_by_side > 1 ? 350 : 500)) / 1000.0 / side_by_side;
+    const double overhead = double(overhead_rows) + 8.0;
     double rows = std::sqrt(double(out_rows) * double(n_strips) * overhead / (alpha * slots));
     rows = std::max(rows, 1.0);
     long chunks = std::max<long>(1, long(double(out_rows) / rows + 0.5));
     // snap to a whole number of residency rounds (just below it) when that is a small change:
-    // a launch of k*S + a few waves pays for a nearly empty extra round
+    // a launch of k*S + a few units pays for a nearly empty extra round
     const double rounds = double(chunks) * n_strips / slots;
     if (rounds >= 0.75) {
         const long k = std::max<long>(1, long(rounds + 0.5));
@@ -1025,30 +891,30 @@ inline int pick_chunk_rows(int out_rows, unsigned n_strips, int halo_rows, int r
 }
 
 // Chunk lengths of a launch.  All chunks have g.chunk_rows rows, except that the tail of the wave grid is
-// cut finer: STSTHIP_TAPER = "permille:split[,permille:split...]" makes the last `permille` of the rows
+// cut finer: the taper "permille:split[,permille:split...]" makes the last `permille` of the rows
 // chunks of chunk_rows/split rows (later entries refine the end further; they must shrink).
+// Default (profiles/r01_tune_taper.txt): the last 12 % of the rows in quarter-length chunks when the
+// launch has the chip to itself (+7 % for a full-grid Jacobi launch, +2..4 % HotSpot / FDTD); launches
+// that run side by side already fill each other's ends and lose 1-6 % with shorter chunks.
 inline void plan_tiers(SweepGeometry &g, int out_rows) {
+    ststhip_options const &opt = options();
     g.n_tiers = 1;
     g.tier_first[0] = 0;
     g.tier_rows[0] = g.chunk_rows;
     g.tier_begin[0] = g.out_begin;
-    // Default (profiles/r01_tune_taper.txt): the last 12 % of the rows in quarter-length chunks when the
-    // launch has the chip to itself (+7 % for a full-grid Jacobi launch, +2..4 % HotSpot / FDTD); launches
-    // that run side by side already fill each other's ends and lose 1-6 % with shorter chunks.
-    const char *spec = std::getenv("STSTHIP_TAPER");
-    std::string text = spec ? spec : (ststhip_launch_concurrency() == 1 ? "120:4" : "150:2");
+    int n_entries = opt.n_taper;
+    int permilles[3] = {opt.taper_permille[0], opt.taper_permille[1], opt.taper_permille[2]};
+    int splits[3] = {opt.taper_split[0], opt.taper_split[1], opt.taper_split[2]};
+    if (n_entries < 0) { // not set in the environment
+        n_entries = 1;
+        permilles[0] = ststhip_launch_concurrency() == 1 ? 120 : 150;
+        splits[0] = ststhip_launch_concurrency() == 1 ? 4 : 2;
+    }
     int done_rows = 0; // rows covered by the tiers closed so far
     unsigned done_chunks = 0;
-    std::size_t at = 0;
     int previous_start = 0;
-    while (at < text.size() && g.n_tiers < unsigned(SweepGeometry::max_tiers)) {
-        const int permille = std::atoi(text.c_str() + at);
-        const std::size_t colon = text.find(':', at);
-        if (colon == std::string::npos)
-            break;
-        const int split = std::atoi(text.c_str() + colon + 1);
-        const std::size_t comma = text.find(',', colon);
-        at = comma == std::string::npos ? text.size() : comma + 1;
+    for (int e = 0; e < n_entries && g.n_tiers < unsigned(SweepGeometry::max_tiers); e++) {
+        const int permille = permilles[e], split = splits[e];
         const int rows = (g.chunk_rows + std::max(split, 1) - 1) / std::max(split, 1);
         // the tier starts at a chunk boundary of the tier before it
         const int current = g.tier_rows[g.n_tiers - 1];
@@ -1069,8 +935,6 @@ inline void plan_tiers(SweepGeometry &g, int out_rows) {
     g.tier_first[g.n_tiers] = g.n_chunks;
 }
 
-template <typename SW> constexpr int P_rows() { return SW::prefetch_depth; }
-
 // One kernel launch = T generations over global rows [out_begin, out_end).  `tdv`: the T time-dependent values
 // evaluated on the host, or nullptr when the kernel takes them from the pass driver's device table
 // (ststhip_current_tdv_table) or evaluates them itself (INLINE_TDV).
@@ -1081,22 +945,19 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
                   std::uint64_t out_end, std::uint64_t iteration, ststhip_stream stream) {
     using Tuning = SweepTuning<F, SOA>;
     using SW = SweepOf<F, SOA, T, INLINE_TDV>;
-    constexpr bool coop = cooperative_for<F, SOA>();
     if (out_end <= out_begin || dom.global_width == 0)
         return;
+    ststhip_options const &opt = options();
     // a driver may leave a hole in the row range (ststhip_launch_row_hole): the two boundary bands of a row strip as
     // ONE launch -- rows [out_begin, hole) and [hole end, out_end), the interior in between is another launch's
     std::uint64_t hole_begin = 0, hole_end = 0;
     ststhip_launch_row_hole(&hole_begin, &hole_end);
     if constexpr (has_narrow_form<F, SOA>()) {
         // grids that cannot fill the chip with this shape: the same function on the narrowest lanes.  So are launches
-        // of a few rows -- the boundary bands of row strips: a band is a dependent chain of 3g row steps per wave that
-        // runs beside a busy interior, and with one cell per lane instead of several a step is that much shorter
-        // (the next pass of two strips and the ghost-row exchange wait for it)
-        static const std::uint64_t narrow_form_cells = std::uint64_t(env_int("STSTHIP_NARROW_FORM_KCELLS", 20000)) * 1000;
-        static const std::uint64_t narrow_band_rows = std::uint64_t(env_int("STSTHIP_NARROW_BAND_ROWS", 0));
+        // of a few rows when asked for (the boundary bands of row strips)
         const std::uint64_t launch_rows = (out_end - out_begin) - (hole_end - hole_begin);
-        if (dom.global_height * dom.global_width <= narrow_form_cells || launch_rows <= narrow_band_rows) {
+        if (dom.global_height * dom.global_width <= std::uint64_t(opt.narrow_form_kcells) * 1000 ||
+            launch_rows <= std::uint64_t(opt.narrow_band_rows)) {
             launch_sweep<NarrowForm<F>, SOA, T, INLINE_TDV>(NarrowForm<F>(f), halo, tdv, dom, src, dst, out_begin, out_end,
                                                             iteration, stream);
             return;
@@ -1120,21 +981,24 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     static std::atomic<int> resident_blocks_cache{0};
     int resident_blocks = resident_blocks_cache.load(std::memory_order_relaxed);
     if (resident_blocks == 0) {
-        check(ststhip_occupancy(kernel, waves_per_block * wave_size, 0, &resident_blocks), "occupancy query");
+        check(ststhip_occupancy(kernel, SW::block_waves * wave_size, 0, &resident_blocks), "occupancy query");
         resident_blocks_cache.store(resident_blocks, std::memory_order_relaxed);
     }
     // per-field planes of fields F only copies: from the third pass of a run on the target holds them already
     if constexpr (SOA && constant_plane_mask<F>() != 0)
-        if (ststhip_target_holds_constants() && env_int("STSTHIP_SKIP_CONSTANT_STORES", 1))
+        if (ststhip_target_holds_constants() && opt.skip_constant_stores)
             kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, true>);
-    g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW); // units: waves, or workgroups (coop)
+    g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW); // units: waves, or workgroups (staged)
+    // rows a unit spends besides its output: 2G warm-up rows, and the skew of a staged pipeline (stage s starts s
+    // batches late)
+    const int overhead_rows = 2 * SW::G + (SW::W - 1) * SW::prefetch_depth;
     if (hole_begin < hole_end) {
         if (hole_begin <= out_begin || hole_end >= out_end)
             throw std::invalid_argument("the row hole must lie strictly inside the launch's row range");
         const int part[2] = {int(hole_begin - out_begin), int(out_end - hole_end)};
         const std::uint64_t part_begin[2] = {out_begin, hole_end};
-        const int wanted = pick_chunk_rows(std::max(part[0], part[1]), coop ? g.n_strips * waves_per_block : g.n_strips,
-                                           SW::G, resident_blocks, int(waves_per_block));
+        const int wanted = pick_chunk_rows(std::max(part[0], part[1]), g.n_strips, overhead_rows, resident_blocks,
+                                           SW::units_per_block);
         g.n_tiers = 2;
         unsigned first = 0;
         for (int t = 0; t < 2; t++) {
@@ -1151,20 +1015,19 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         g.n_chunks = first;
         g.chunk_rows = std::max(g.tier_rows[0], g.tier_rows[1]);
     } else {
-        g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), coop ? g.n_strips * waves_per_block : g.n_strips,
-                                       SW::G, resident_blocks, int(waves_per_block));
+        g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), g.n_strips, overhead_rows, resident_blocks,
+                                       SW::units_per_block);
         g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
         plan_tiers(g, int(out_end - out_begin));
     }
     if (dom.pitch >= (1ull << 31))
         throw std::range_error("the pitch must be below 2^31 elements");
-    g.pitch = dom.pitch;
     g.pitch32 = std::uint32_t(dom.pitch);
     g.iteration = iteration;
     // measured (profiles/r01_xcd_remap.txt): 4 % fewer HBM reads, but no gain in time for these
     // VALU-bound kernels, so the remap is off unless asked for
-    g.xcd_remap = env_int("STSTHIP_XCD_REMAP", 0) ? 1u : 0u;
-    g.last_chunk_early = (out_end + SW::G > dom.global_height && env_int("STSTHIP_LAST_CHUNK_EARLY", 1)) ? 1u : 0u;
+    g.xcd_remap = opt.xcd_remap ? 1u : 0u;
+    g.last_chunk_early = (out_end + SW::G > dom.global_height && opt.last_chunk_early) ? 1u : 0u;
 
     using TDV = typename F::TimeDependentValue;
     TDV const *table = nullptr;
@@ -1178,59 +1041,15 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         else if (!tdv)
             throw std::invalid_argument("no time-dependent values for this launch");
     }
-    // persistent waves: one residency round of waves that claim fine row chunks and continue downwards
-    void *claim_words = nullptr;
-    bool persistent = false;
-    g.fine_rows = g.n_fine = g.starts_per_strip = g.start_stride = g.phase_step = g.cursor_end = 0;
-    g.claims = g.cursor = nullptr;
-    if constexpr (persistent_for<F, SOA>() && SW::can_continue) {
-        const int rows = int(out_end - out_begin);
-        int fine = env_int("STSTHIP_FINE_ROWS", 32);
-        fine = round_up(std::max(fine, P_rows<SW>()), P_rows<SW>());
-        if (env_int("STSTHIP_PERSISTENT", 1) && rows >= 8 * fine && hole_begin == hole_end) {
-            int cus = 256;
-            ststhip_compute_units(&cus);
-            std::uint32_t slots = std::uint32_t(cus) * std::uint32_t(std::max(resident_blocks, 1)) * waves_per_block /
-                                  std::uint32_t(std::max(1, ststhip_launch_concurrency()));
-            slots = std::uint32_t(std::uint64_t(slots) * std::uint64_t(env_int("STSTHIP_PERSISTENT_FILL_PERMILLE", 1000)) / 1000);
-            g.fine_rows = std::uint32_t(fine);
-            g.n_fine = std::uint32_t((rows + fine - 1) / fine);
-            g.starts_per_strip = std::min(std::max(slots / g.n_strips, 1u), g.n_fine);
-            g.start_stride = (g.n_fine + g.starts_per_strip - 1) / g.starts_per_strip;
-            g.phase_step = std::max(1u, g.start_stride / std::uint32_t(std::max(1, env_int("STSTHIP_PERSISTENT_PHASES", 4))));
-            g.cursor_end = ((g.start_stride + g.phase_step - 1) / g.phase_step) * g.starts_per_strip * g.n_strips;
-            const std::size_t n_words = std::size_t(g.n_fine) * g.n_strips;
-            check(ststhip_malloc_async(&claim_words, n_words * 4, stream), "claim table");
-            check(ststhip_memset(claim_words, 0, n_words * 4, stream), "claim table");
-            g.claims = static_cast<std::uint32_t *>(claim_words);
-            g.cursor = nullptr;
-            kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, false, true>);
-            if constexpr (SOA && constant_plane_mask<F>() != 0)
-                if (ststhip_target_holds_constants() && env_int("STSTHIP_SKIP_CONSTANT_STORES", 1))
-                    kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, true, true>);
-            persistent = true;
-        }
-    }
     // transition functions need not be default-constructible: build the argument block in one go
     typename SW::Args args = [&]<std::size_t... Is>(std::index_sequence<Is...>) {
-        return typename SW::Args{f, halo, {((table || !tdv) ? TDV{} : tdv[Is])...}, table, src, dst, g};
+        return typename SW::Args{{((table || !tdv) ? TDV{} : tdv[Is])...}, table, f, halo, src, dst, g};
     }(std::make_index_sequence<std::size_t(T)>{});
 
     const unsigned units = g.n_strips * g.n_chunks;
-    unsigned blocks = coop ? units : (units + waves_per_block - 1) / waves_per_block;
-    if (persistent) {
-        int cus = 256;
-        ststhip_compute_units(&cus);
-        const unsigned resident = unsigned(cus) * unsigned(std::max(resident_blocks, 1)) /
-                                  unsigned(std::max(1, ststhip_launch_concurrency()));
-        (void)resident;
-        blocks = std::max(1u, (g.cursor_end + waves_per_block - 1) / waves_per_block); // one wave per ticket
-    }
+    const unsigned blocks = (units + SW::units_per_block - 1) / SW::units_per_block;
     void *kernel_args[] = {&args};
-    const int launched = ststhip_launch(kernel, blocks, 1, 1, waves_per_block * wave_size, 1, 1, kernel_args, 0, stream);
-    if (claim_words)
-        ststhip_free_async(claim_words, stream); // released behind the launch
-    check(launched, "sweep launch");
+    check(ststhip_launch(kernel, blocks, 1, 1, SW::block_waves * wave_size, 1, 1, kernel_args, 0, stream), "sweep launch");
 }
 
 // Runtime n_generations -> compiled T (powers of two up to the tuning's maximum).
@@ -1253,7 +1072,7 @@ void dispatch_sweep(int n_generations, F const &f, typename F::Cell const &halo,
 // Largest compiled depth that fits into `remaining` generations.
 template <typename F, bool SOA> inline int next_pass_depth(std::uint64_t remaining) {
     int t = SweepTuning<F, SOA>::max_generations;
-    int cap = env_int("STSTHIP_MAX_GENERATIONS", t);
+    const int cap = options().max_generations > 0 ? options().max_generations : t;
     while (t > 1 && (std::uint64_t(t) > remaining || t > cap))
         t /= 2;
     return t;

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STSTHIP_ABI_VERSION 3
+#define STSTHIP_ABI_VERSION 4
 
 typedef enum {
     STSTHIP_OK = 0,
@@ -145,6 +145,36 @@ int ststhip_set_launch_row_hole(uint64_t begin, uint64_t end);
  * grid, for callers that drive ststhip_app_sweep themselves.  Returns 1 for unknown apps. */
 int ststhip_suggest_row_strips(const char *app, uint64_t rows, uint64_t width, uint64_t n_passes);
 
+/* Tuning knobs of the launcher and the drivers.  They come from the environment (STSTHIP_<NAME>, upper case) ONCE,
+ * when the runtime first needs them (ststhip_init), never per launch; a host that changes its environment afterwards
+ * (tools, tests) calls ststhip_reload_options().  0 / -1 = "not set, use the built-in rule" where noted.  Every knob
+ * changes speed only, never results. */
+typedef struct {
+    int32_t chunk_rows;            /* rows of output per wave; 0 = the launcher's rule                    */
+    int32_t tail_permille;         /* weight of a launch's ragged tail in that rule; 0 = built-in         */
+    int32_t n_taper;               /* entries of STSTHIP_TAPER="permille:split,..."; -1 = built-in        */
+    int32_t taper_permille[3], taper_split[3];
+    int32_t narrow_form_kcells;    /* grids up to this many thousand cells run the one-cell-per-lane form */
+    int32_t narrow_band_rows;      /* so do launches of at most this many rows (0 = never)                */
+    int32_t skip_constant_stores;  /* leave out the stores of F::constant_fields where the target holds them */
+    int32_t xcd_remap, last_chunk_early;
+    int32_t max_generations;       /* cap of the temporal-blocking depth; 0 = the compiled maximum        */
+    int32_t allow_spilling_depths; /* C++ templates: also use depths whose kernel spills registers        */
+    int32_t virtual_strips;        /* row strips of the pass driver; 0 = its rule                         */
+    int32_t two_strips_permille, two_strips_permille_outer; /* thresholds of that rule                    */
+    int32_t strip_skew_permille;   /* where the pass driver cuts two strips; 0 = built-in                 */
+    int32_t bands_beside_interior, band_stream_priority, bands_apart, bands_one_launch, comm_stream_priority;
+    int32_t jacobi_fastpath, conway_fastpath;
+    int32_t prepare_streams;       /* create and first-use the pass driver's streams at ststhip_init      */
+    int32_t host_cache_mib;        /* free pinned host blocks kept for reuse                              */
+    int32_t pretend_neighbours;    /* EXPERIMENTS builds only (timing studies on one GPU); 0 otherwise    */
+    int32_t exchange_every;        /* strip driver: exchange m*g ghost rows every m-th launch; 0/1 = every launch */
+    int32_t upload_strips;         /* hip::Grid upload in this many row strips overlapped with the first pass; 0 = rule */
+    int32_t reserved[6];
+} ststhip_options;
+const ststhip_options *ststhip_get_options(void);
+int ststhip_reload_options(void);
+
 /* AoS <-> per-field planes by byte geometry (the reference's scatter/gather kernels,
  * StencilStream/cuda/StencilUpdate.hpp:294-321 and :408-438).  Field f of cell i is the
  * `field_size[f]` bytes at aos + i*cell_size + field_offset[f]; plane f holds them densely.
@@ -202,10 +232,10 @@ typedef struct {
     uint32_t max_generations;    /* deepest temporal blocking compiled in                */
     uint32_t tdv_size;           /* 0 = no time-dependent value                          */
     uint32_t halo_depth_per_generation; /* ghost rows one generation consumes per side   */
-    uint32_t strip_width;        /* columns one wavefront produces at max_generations (cooperative: a quarter of its workgroup's) */
+    uint32_t strip_width;        /* columns one wavefront produces at max_generations (staged sweeps: its share of the workgroup's strip) */
     uint32_t cells_per_lane;     /* adjacent cells a lane holds per row (K)              */
     uint32_t prefetch_rows;      /* rows loaded ahead of the pipeline (P)                */
-    uint32_t cooperative;        /* 1: the waves of a workgroup share their edge columns through LDS */
+    uint32_t stages;             /* waves of a workgroup that share one column strip as a pipeline over the levels (1 = independent waves) */
 } ststhip_app_info;
 
 int ststhip_app_count(void);

@@ -58,7 +58,7 @@ class AppInfo(C.Structure):
         ("strip_width", C.c_uint32),
         ("cells_per_lane", C.c_uint32),
         ("prefetch_rows", C.c_uint32),
-        ("cooperative", C.c_uint32),
+        ("stages", C.c_uint32),
     ]
 
 
@@ -124,6 +124,19 @@ class NoParams(C.Structure):
     _fields_ = [("unused", C.c_int)]
 
 
+class Options(C.Structure):
+    """ststhip_options (include/ststhip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("chunk_rows", "tail_permille", "n_taper")] + \
+               [("taper_permille", C.c_int32 * 3), ("taper_split", C.c_int32 * 3)] + \
+               [(n, C.c_int32) for n in (
+                   "narrow_form_kcells", "narrow_band_rows", "skip_constant_stores", "xcd_remap", "last_chunk_early",
+                   "max_generations", "allow_spilling_depths", "virtual_strips", "two_strips_permille",
+                   "two_strips_permille_outer", "strip_skew_permille", "bands_beside_interior", "band_stream_priority",
+                   "bands_apart", "bands_one_launch", "comm_stream_priority", "jacobi_fastpath", "conway_fastpath",
+                   "prepare_streams", "host_cache_mib", "pretend_neighbours", "exchange_every", "upload_strips")] + \
+               [("reserved", C.c_int32 * 6)]
+
+
 _lib = None
 
 
@@ -151,6 +164,7 @@ def load():
     sigs = {
         "ststhip_abi_version": [],
         "ststhip_init": [C.c_int],
+        "ststhip_reload_options": [],
         "ststhip_shutdown": [],
         "ststhip_device_count": [C.POINTER(C.c_int)],
         "ststhip_device_name": [C.c_char_p, sz],
@@ -216,6 +230,8 @@ def load():
         fn.argtypes = argtypes
         if name != "ststhip_last_error":
             fn.restype = C.c_int
+    lib.ststhip_get_options.argtypes = []
+    lib.ststhip_get_options.restype = C.POINTER(Options)
     _lib = lib
     return lib
 
@@ -235,6 +251,30 @@ def check(status, what):
 
 def init(device=-1):
     check(load().ststhip_init(int(device)), "ststhip_init")
+
+
+_env_seen = None
+
+
+def _sync_options():
+    """The library reads its STSTHIP_* knobs once; Python hosts (tests, tuning tools) change os.environ between
+    calls, so the binding re-reads them when that part of the environment has changed since its last call."""
+    global _env_seen
+    now = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("STSTHIP_")))
+    if now != _env_seen:
+        if _env_seen is not None or now:
+            load().ststhip_reload_options()
+        _env_seen = now
+
+
+def reload_options():
+    """Re-read the STSTHIP_* tuning knobs from the environment (they are read once, at first use)."""
+    check(load().ststhip_reload_options(), "ststhip_reload_options")
+
+
+def options():
+    """The tuning knobs in effect (ststhip_options of include/ststhip.h)."""
+    return load().ststhip_get_options().contents
 
 
 def app_info(name):
@@ -294,6 +334,7 @@ def _ptr_array(pointers):
 def app_sweep(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, out_begin, out_end, iteration,
               n_generations, stream=0):
     """One launch: n_generations generations over global rows [out_begin, out_end)."""
+    _sync_options()
     halo = C.create_string_buffer(bytes(halo_bytes), len(halo_bytes))
     src = _ptr_array(src_ptrs)
     dst = _ptr_array(dst_ptrs)
@@ -314,6 +355,7 @@ def app_run(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, iteration_offse
     The work is queued on `stream` (0 = the library's own stream), which is NOT torch's current stream: tensors that
     torch kernels have just filled or cleared must be complete first (torch.cuda.synchronize(), an event, or the
     `on_stream` helper below), or the sweep races with them."""
+    _sync_options()
     halo = C.create_string_buffer(bytes(halo_bytes), len(halo_bytes))
     src = _ptr_array(src_ptrs)
     dst = _ptr_array(dst_ptrs)
@@ -377,6 +419,7 @@ class Strip:
     pointers of ststhip_comm_exchange_rows, for hosts whose ranks RCCL cannot join (tests)."""
 
     def __init__(self, app, tf_params, halo_bytes, total_rows, width, rank, n_ranks, comm=None, exchange=None):
+        _sync_options()
         self._callback = None
         cb = None
         if exchange is not None:
@@ -441,6 +484,7 @@ class Strip:
         check(load().ststhip_strip_warm_up(self.handle), "ststhip_strip_warm_up")
 
     def advance(self, iteration_offset, n_generations, blocking=False):
+        _sync_options()
         check(load().ststhip_strip_advance(self.handle, int(iteration_offset), int(n_generations), int(bool(blocking))),
               "ststhip_strip_advance")
 

@@ -97,7 +97,7 @@ template <typename F, bool SOA> struct AppAdapter {
         e.info.strip_width = std::uint32_t(stencil::hip::internal::SweepOf<F, SOA>::OW_PER_WAVE);
         e.info.cells_per_lane = std::uint32_t(Tuning::cells_per_lane);
         e.info.prefetch_rows = std::uint32_t(Tuning::prefetch_rows);
-        e.info.cooperative = stencil::hip::internal::cooperative_for<F, SOA>() ? 1u : 0u;
+        e.info.stages = std::uint32_t(stencil::hip::internal::SweepOf<F, SOA>::W);
         e.sweep = &sweep;
         e.fill_tdv = e.info.tdv_size ? &fill_tdv : nullptr;
         return e;
@@ -105,9 +105,9 @@ template <typename F, bool SOA> struct AppAdapter {
 };
 
 // A transition function with an explicit pipeline shape (used to register tuning experiments and
-// hand-picked shapes next to the heuristic default).
-template <typename F, int K, int T, int P, int MINW = 1, bool INTERIOR = true, bool COOP = false, int DBG = 0,
-          bool PERSIST = false>
+// hand-picked shapes next to the heuristic default).  STAGES: waves of a workgroup that share one column strip as
+// a pipeline over the levels (Sweep.hpp).  An explicit shape is launched as it is: no narrow form.
+template <typename F, int K, int T, int P, int MINW = 1, bool INTERIOR = true, int STAGES = 1>
 struct Shaped : public F {
     using Block = typename F::Block;
     Shaped() = default;
@@ -123,16 +123,15 @@ struct AppRegistrar {
 
 namespace stencil {
 namespace hip {
-template <typename F, int K, int T, int P, int MINW, bool INTERIOR, bool COOP, int DBG, bool PERSIST, bool SOA>
-struct SweepTuning<::ststhip_detail::Shaped<F, K, T, P, MINW, INTERIOR, COOP, DBG, PERSIST>, SOA> {
-    static constexpr int cooperative_debug = DBG;
-    static constexpr bool persistent = PERSIST;
+template <typename F, int K, int T, int P, int MINW, bool INTERIOR, int STAGES, bool SOA>
+struct SweepTuning<::ststhip_detail::Shaped<F, K, T, P, MINW, INTERIOR, STAGES>, SOA> {
     static constexpr int cells_per_lane = K;
     static constexpr int max_generations = T;
     static constexpr int prefetch_rows = P;
     static constexpr bool interior_variant = INTERIOR;
     static constexpr int min_waves_per_simd = MINW;
-    static constexpr bool cooperative = COOP;
+    static constexpr int stages = STAGES;
+    static constexpr bool narrow_form = false;
     // hints the wrapped function's own tuning carries
     static constexpr bool trapezoid_fill = internal::trapezoid_fill_for<F, SOA>();
     static constexpr bool streaming_stores = internal::streaming_stores_for<F, SOA>();

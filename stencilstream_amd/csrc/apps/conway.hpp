@@ -69,6 +69,7 @@ template <> struct SweepTuning<apps::ConwayPacked, false> {
     static constexpr bool interior_variant = true;
     static constexpr int min_waves_per_simd = 1;
     static constexpr bool streaming_stores = false;
+    static constexpr int stages = 4; // 16384^2: 9620 -> 12370 Gcell/s (profiles/r03_tune_staged.txt)
 };
 } // namespace hip
 } // namespace stencil

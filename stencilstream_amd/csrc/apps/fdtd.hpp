@@ -148,21 +148,25 @@ struct FdtdGrouped {
 
 namespace hip {
 template <typename F, bool SOA> struct SweepTuning;
+// Independent waves (rounds 1 and 2; profiles/r01_tune_shapes_apps.txt, 4608^2): K = 1 with T = 4, P = 4: 270 / 231
+// (AoS / planes), T = 6, P = 2: 347 / 284, T = 7: 234 (register cliff) Gcell/s.  Round 3, four stages per column strip
+// (a wave keeps the windows of S/4 levels only, so the launch can be deeper): AoS T = 6: 378 -> 409, T = 8: 464;
+// the two-plane layout T = 6: 449 -> 509, T = 8: 509 (profiles/r03_tune_staged.txt).  Launch depths 8, 4, 2, 1.
 template <bool SOA> struct SweepTuning<apps::FdtdGrouped, SOA> {
     static constexpr int cells_per_lane = 1;
-    static constexpr int max_generations = 6;
+    static constexpr int max_generations = 8;
     static constexpr int prefetch_rows = 2;
     static constexpr bool interior_variant = true;
     static constexpr int min_waves_per_simd = 1;
+    static constexpr int stages = 4;
 };
-// Measured (profiles/r01_tune_shapes_apps.txt, 4608^2): K=1 with T=4,P=4: 270 / 231 (AoS / planes),
-// T=5,P=2: 314 / 244, T=6,P=2: 347 / 284, T=7,P=2: 234 (register cliff) Gcell/s.  Launch depths 6, 3, 1.
 template <bool SOA> struct SweepTuning<apps::Fdtd, SOA> {
     static constexpr int cells_per_lane = 1;
-    static constexpr int max_generations = 6;
+    static constexpr int max_generations = 8;
     static constexpr int prefetch_rows = 2;
     static constexpr bool interior_variant = true;
     static constexpr int min_waves_per_simd = 1;
+    static constexpr int stages = 4;
 };
 } // namespace hip
 } // namespace stencil

@@ -79,4 +79,27 @@ using HotspotCell = HotspotCellT<float>;
 using Hotspot = HotspotT<float>;
 
 } // namespace apps
+
+namespace hip {
+template <typename F, bool SOA> struct SweepTuning;
+// fp32 HotSpot, 8192^2 (profiles/r03_tune_staged.txt): the independent-wave shapes K = 1, T = 8 on planes 1777 and
+// K = 2, T = 8 as AoS 1821 Gcell/s; four stages per column strip: planes K = 2, T = 12: 2090 (K = 1, T = 8: 1750,
+// K = 2, T = 8: 1820, K = 2, T = 16: 1940, K = 4, T = 12: 1950), AoS K = 2, T = 16: 1970 (T = 8: 1810).
+template <> struct SweepTuning<apps::HotspotT<float>, true> {
+    static constexpr int cells_per_lane = 2;
+    static constexpr int max_generations = 12;
+    static constexpr int prefetch_rows = 4;
+    static constexpr bool interior_variant = true;
+    static constexpr int min_waves_per_simd = 1;
+    static constexpr int stages = 4;
+};
+template <> struct SweepTuning<apps::HotspotT<float>, false> {
+    static constexpr int cells_per_lane = 2;
+    static constexpr int max_generations = 16;
+    static constexpr int prefetch_rows = 4;
+    static constexpr bool interior_variant = true;
+    static constexpr int min_waves_per_simd = 1;
+    static constexpr int stages = 4;
+};
+} // namespace hip
 } // namespace stencil

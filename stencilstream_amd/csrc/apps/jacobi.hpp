@@ -165,16 +165,19 @@ template <> struct SweepTuning<apps::Jacobi<apps::JacobiVariant::General9>, fals
     static constexpr bool interior_variant = true;
     static constexpr int min_waves_per_simd = 1;
 };
-// With 5 flops per cell the kernel is HBM bound at 8 generations per launch; 12 generations on 3 cells
-// per lane is the measured optimum (profiles/r01_tune_jacobi_uniform.txt: K=4,T=8: 4.4, K=2,T=16: 5.1,
-// K=4,T=12: 5.3, K=3,T=12: 5.5, K=3,T=16: 5.0 Tcell/s).  Launch depths: 12 and its halvings 6, 3, 1.
+// With 5 flops per cell the kernel is HBM bound at 8 generations per launch; 12 generations per launch (launch depths
+// 12 and its halvings 6, 3, 1) on 3 cells per lane was the optimum of the independent-wave sweep
+// (profiles/r01_tune_jacobi_uniform.txt).  Round 3: four stages per column strip (three levels per wave) leave room
+// for 4 cells per lane at six waves per SIMD -- 16384^2: 5690 -> 6000 Gcell/s as single launches, 2048 x 16384 (the
+// strip of an 8-GPU run): 3190 -> 4090, 1000 x 1500: 570 -> 710 (profiles/r03_tune_staged.txt).
 template <bool FirstLaunch, bool LastLaunch>
 struct SweepTuning<apps::Jacobi5Uniform<FirstLaunch, LastLaunch>, false> {
-    static constexpr int cells_per_lane = 3;
+    static constexpr int cells_per_lane = 4;
     static constexpr int max_generations = 12;
     static constexpr int prefetch_rows = 4;
     static constexpr bool interior_variant = true;
     static constexpr int min_waves_per_simd = 1;
+    static constexpr int stages = 4;
 };
 } // namespace hip
 } // namespace stencil

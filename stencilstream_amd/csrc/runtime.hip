@@ -32,6 +32,68 @@ static int hip_fail(hipError_t err, const char *what) {
     return STSTHIP_ERR_HIP;
 }
 
+// ------------------------------------------------------------------ options (environment, read once)
+static int env_int(const char *name, int fallback) {
+    const char *v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : fallback;
+}
+static ststhip_options read_options() {
+    ststhip_options o;
+    std::memset(&o, 0, sizeof o);
+    o.chunk_rows = env_int("STSTHIP_CHUNK_ROWS", 0);
+    o.tail_permille = env_int("STSTHIP_TAIL_PERMILLE", 0);
+    o.n_taper = -1;
+    if (const char *spec = std::getenv("STSTHIP_TAPER")) {
+        // "permille:split[,permille:split...]" (Sweep.hpp, plan_tiers); an empty string switches the taper off
+        std::string text = spec;
+        o.n_taper = 0;
+        std::size_t at = 0;
+        while (at < text.size() && o.n_taper < 3) {
+            const std::size_t colon = text.find(':', at);
+            if (colon == std::string::npos)
+                break;
+            o.taper_permille[o.n_taper] = std::atoi(text.c_str() + at);
+            o.taper_split[o.n_taper] = std::atoi(text.c_str() + colon + 1);
+            o.n_taper++;
+            const std::size_t comma = text.find(',', colon);
+            at = comma == std::string::npos ? text.size() : comma + 1;
+        }
+    }
+    o.narrow_form_kcells = env_int("STSTHIP_NARROW_FORM_KCELLS", 20000);
+    o.narrow_band_rows = env_int("STSTHIP_NARROW_BAND_ROWS", 0);
+    o.skip_constant_stores = env_int("STSTHIP_SKIP_CONSTANT_STORES", 1);
+    o.xcd_remap = env_int("STSTHIP_XCD_REMAP", 0);
+    o.last_chunk_early = env_int("STSTHIP_LAST_CHUNK_EARLY", 1);
+    o.max_generations = env_int("STSTHIP_MAX_GENERATIONS", 0);
+    o.allow_spilling_depths = env_int("STSTHIP_ALLOW_SPILLING_DEPTHS", 0);
+    o.virtual_strips = env_int("STSTHIP_VIRTUAL_STRIPS", 0);
+    o.two_strips_permille = env_int("STSTHIP_TWO_STRIPS_PERMILLE", 1220);
+    o.two_strips_permille_outer = env_int("STSTHIP_TWO_STRIPS_PERMILLE", 1500);
+    o.strip_skew_permille = env_int("STSTHIP_STRIP_SKEW_PERMILLE", 0);
+    o.bands_beside_interior = env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1);
+    o.band_stream_priority = env_int("STSTHIP_BAND_STREAM_PRIORITY", 1);
+    o.bands_apart = env_int("STSTHIP_BANDS_APART", 0);
+    o.bands_one_launch = env_int("STSTHIP_BANDS_ONE_LAUNCH", 1);
+    o.comm_stream_priority = env_int("STSTHIP_COMM_STREAM_PRIORITY", 0);
+    o.jacobi_fastpath = env_int("STSTHIP_JACOBI_FASTPATH", 1);
+    o.conway_fastpath = env_int("STSTHIP_CONWAY_FASTPATH", 1);
+    o.prepare_streams = env_int("STSTHIP_PREPARE_STREAMS", 0);
+    o.host_cache_mib = env_int("STSTHIP_HOST_CACHE_MIB", 4096);
+#ifdef STSTHIP_EXPERIMENTS
+    // timing studies on one GPU: launch the bands a strip with neighbours on both sides launches, without the
+    // exchange -- the rows at the strip's ends are then WRONG, which is why the product build has no such switch
+    o.pretend_neighbours = env_int("STSTHIP_STRIP_PRETEND_NEIGHBOURS", 0);
+#endif
+    o.exchange_every = env_int("STSTHIP_EXCHANGE_EVERY", 0);
+    o.upload_strips = env_int("STSTHIP_UPLOAD_STRIPS", 0);
+    return o;
+}
+static ststhip_options &options_storage() {
+    static ststhip_options o = read_options();
+    return o;
+}
+static const ststhip_options &opt() { return options_storage(); }
+
 #define HIP_TRY(call)                                                                              \
     do {                                                                                           \
         hipError_t err_ = (call);                                                                  \
@@ -63,12 +125,43 @@ struct Runtime {
 };
 // free pinned blocks kept for reuse, at most (pinned memory is taken from the host's RAM)
 static std::size_t host_cache_limit() {
-    return std::size_t(stencil::hip::internal::env_int("STSTHIP_HOST_CACHE_MIB", 4096)) << 20;
+    return std::size_t(opt().host_cache_mib) << 20;
 }
 static Runtime &rt() {
     static Runtime r;
     return r;
 }
+
+// Events of the drivers (hipEventDisableTiming), recycled: a 1000-generation call records about 500, and creating and
+// destroying each one showed in the launch gaps of small grids.  A driver call takes events from the process-wide free
+// list and hands them all back when it returns: by then every wait on them has been ENQUEUED (hipStreamWaitEvent
+// captures the record it waits for at enqueue time), so recording them again in a later call is safe.
+struct EventPool {
+    std::vector<hipEvent_t> taken;
+    static std::vector<hipEvent_t> &free_list() {
+        static std::vector<hipEvent_t> list;
+        return list;
+    }
+    hipEvent_t take() {
+        hipEvent_t ev = nullptr;
+        {
+            std::lock_guard<std::mutex> guard(rt().lock);
+            if (!free_list().empty()) {
+                ev = free_list().back();
+                free_list().pop_back();
+            }
+        }
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+        taken.push_back(ev);
+        return ev;
+    }
+    ~EventPool() {
+        std::lock_guard<std::mutex> guard(rt().lock);
+        for (hipEvent_t ev : taken)
+            free_list().push_back(ev);
+    }
+};
 
 // Side streams of the pass driver (row strips advancing concurrently).  Every caller stream gets its own
 // set, created on demand under the runtime lock: two host threads (or two torch streams) that run the pass
@@ -97,7 +190,7 @@ static std::map<hipStream_t, std::vector<hipStream_t>> &band_streams() {
     return streams;
 }
 static hipError_t create_band_stream(hipStream_t *stream) {
-    if (!stencil::hip::internal::env_int("STSTHIP_BAND_STREAM_PRIORITY", 1)) // A/B: bands on normal-priority streams
+    if (!opt().band_stream_priority) // A/B: bands on normal-priority streams
         return hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
@@ -376,6 +469,12 @@ int ststhip_abi_version(void) { return STSTHIP_ABI_VERSION; }
 const char *ststhip_last_error(void) { return g_last_error.c_str(); }
 void ststhip_set_last_error(const char *message) { set_error(message); }
 
+const ststhip_options *ststhip_get_options(void) { return &options_storage(); }
+int ststhip_reload_options(void) {
+    options_storage() = read_options();
+    return STSTHIP_OK;
+}
+
 int ststhip_init(int device) {
     Runtime &r = rt();
     std::lock_guard<std::mutex> guard(r.lock);
@@ -402,7 +501,7 @@ int ststhip_init(int device) {
     // one-shot 1000-generation run of the unchanged jacobi example: 0.121 -> 0.096 s; profiles/r02_short_runs.txt).
     // Off by default: for a caller that brings its OWN stream (bench.py, the Python API) these would be four idle
     // streams in front of its own on the few hardware queues, and its strips collide (bench.py 6500 -> 4280).
-    if (stencil::hip::internal::env_int("STSTHIP_PREPARE_STREAMS", 0)) {
+    if (opt().prepare_streams) {
         std::vector<hipStream_t> made;
         auto &side = side_streams()[r.stream];
         auto &band = band_streams()[r.stream];
@@ -444,6 +543,9 @@ int ststhip_shutdown(void) {
             (void)hipStreamDestroy(extra);
         }
     band_streams().clear();
+    for (hipEvent_t ev : EventPool::free_list())
+        (void)hipEventDestroy(ev);
+    EventPool::free_list().clear();
     release_free_blocks(r);
     for (auto &kv : r.free_host_blocks)
         (void)hipHostFree(kv.second);
@@ -813,12 +915,11 @@ int ststhip_set_launch_concurrency(int n) {
 // only from 1.5 on (Jacobi 4096 x 16384, 1.24: one sub-strip 3990, two 4020; 8192 x 16384, 1.75: 4990 / 5350).
 static int suggest_row_strips(std::uint64_t rows, std::uint64_t width, std::uint32_t strip_width,
                               std::uint64_t g_max, std::uint64_t n_passes, bool outer_bands = false) {
-    int strips = stencil::hip::internal::env_int("STSTHIP_VIRTUAL_STRIPS", 0);
+    int strips = opt().virtual_strips;
     if (strips <= 0) {
         strips = 1;
         if (n_passes >= 2 && strip_width > 0) {
-            const double threshold =
-                stencil::hip::internal::env_int("STSTHIP_TWO_STRIPS_PERMILLE", outer_bands ? 1500 : 1220) / 1000.0;
+            const double threshold = (outer_bands ? opt().two_strips_permille_outer : opt().two_strips_permille) / 1000.0;
             const double n_cols = std::ceil(double(width) / strip_width);
             const double slots = double(rt().compute_units) * 16.0; // ~4 workgroups of 4 waves per CU
             const double chunk = std::sqrt(double(rows) * n_cols * (2.0 * double(g_max) + 8.0) / (0.5 * slots));
@@ -1005,7 +1106,7 @@ int ststhip_app_sweep(const char *app, const void *tf_params, const void *halo_c
 // the tail of one strip's kernel overlap with the next kernels of the other strips.
 static std::vector<std::uint32_t> plan_depths(std::uint64_t n_iterations, std::uint32_t max_generations) {
     std::vector<std::uint32_t> depths;
-    int cap = stencil::hip::internal::env_int("STSTHIP_MAX_GENERATIONS", int(max_generations));
+    const int cap = opt().max_generations > 0 ? opt().max_generations : int(max_generations);
     std::uint64_t remaining = n_iterations;
     while (remaining > 0) {
         std::uint32_t t = max_generations;
@@ -1037,7 +1138,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
 
     const std::vector<std::uint32_t> depths = plan_depths(n_iterations, desc->max_generations);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
-    std::vector<hipEvent_t> sync_events;
+    EventPool sync_events;
     std::uint64_t n_launches = 0;
     int rc = STSTHIP_OK;
     void *scratch[16] = {nullptr};
@@ -1071,8 +1172,9 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                 if (rc == STSTHIP_OK) {
                     std::vector<unsigned char> values(bytes);
                     desc->fill_tdv(ctx, iteration_offset, n_iterations, values.data());
-                    // pageable source: the copy is staged before the call returns
+                    // `values` is pageable and goes out of scope: the copy must have read it before that
                     ordered(hipMemcpyAsync(tdv_table, values.data(), bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync");
+                    ordered(hipStreamSynchronize(s), "hipStreamSynchronize");
                     g_tdv_table = tdv_table;
                 }
             }
@@ -1081,9 +1183,9 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             g_tdv_size = desc->tdv_size;
         }
         auto new_event = [&]() {
-            hipEvent_t e = nullptr;
-            ordered(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
-            sync_events.push_back(e);
+            hipEvent_t e = sync_events.take();
+            if (!e)
+                ordered(hipErrorUnknown, "hipEventCreateWithFlags");
             return e;
         };
         // streams of the strips: strip 0 runs on the caller's stream
@@ -1108,9 +1210,8 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         // unequal strips drift out of phase, so one strip's tail meets the other's bulk (400 while the bands sat in
         // front of the interiors); with the bands beside the interiors equal strips are as good or better
         if (strips == 2)
-            bound[1] = H * std::uint64_t(stencil::hip::internal::env_int(
-                               "STSTHIP_STRIP_SKEW_PERMILLE",
-                               stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1) ? 500 : 400)) / 1000;
+            bound[1] = H * std::uint64_t(opt().strip_skew_permille > 0 ? opt().strip_skew_permille
+                                                                        : (opt().bands_beside_interior ? 500 : 400)) / 1000;
         // Boundary bands on streams of their own (highest priority), beside the interior of the same strip and
         // pass: a band's output only feeds the NEXT pass, and in the strip's own stream it sat in front of the
         // interior for 110-165 us per pass (12 rows of work that queue behind the other strip's resident waves;
@@ -1120,7 +1221,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         // -- every row a launch reads was written by one of those, and every row it overwrites (the other buffer
         // set) was last read by one of those.
         std::vector<hipStream_t> band_lane(strips, nullptr);
-        const bool bands_beside = strips > 1 && stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1) != 0 &&
+        const bool bands_beside = strips > 1 && opt().bands_beside_interior != 0 &&
                                   band_streams_for(s, strips, band_lane);
         if (bands_beside) {
             hipEvent_t begin = new_event();
@@ -1240,8 +1341,6 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    for (hipEvent_t e : sync_events)
-        (void)hipEventDestroy(e);
     if (info) {
         std::chrono::duration<double> elapsed = std::chrono::high_resolution_clock::now() - started;
         info->walltime_s = elapsed.count();
@@ -1330,7 +1429,7 @@ int resolve_app(ResolvedApp &r, const char *app, const void *tf_params, const vo
         return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
     // Jacobi5General with five equal positive coefficients and a +0 halo: bit-identical results from the
     // product-carrying form with 5 instead of 9 flops per cell (apps/jacobi.hpp, Jacobi5Uniform)
-    if (std::strcmp(app, "jacobi5general") == 0 && stencil::hip::internal::env_int("STSTHIP_JACOBI_FASTPATH", 1)) {
+    if (std::strcmp(app, "jacobi5general") == 0 && opt().jacobi_fastpath) {
         const ststhip_jacobi_params *jp = static_cast<const ststhip_jacobi_params *>(tf_params);
         std::uint32_t halo_bits;
         std::memcpy(&halo_bits, halo_cell, sizeof halo_bits);
@@ -1355,7 +1454,7 @@ int resolve_app(ResolvedApp &r, const char *app, const void *tf_params, const vo
         dom->pitch % 4 == 0 && *static_cast<const unsigned char *>(halo_cell) == 0 &&
         (!have_planes || (reinterpret_cast<std::uintptr_t>(src[0]) % 4 == 0 &&
                           reinterpret_cast<std::uintptr_t>(dst[0]) % 4 == 0)) &&
-        stencil::hip::internal::env_int("STSTHIP_CONWAY_FASTPATH", 1)) {
+        opt().conway_fastpath) {
         if (const AppEntry *packed = find_app("conway_packed")) {
             e = packed;
             r.words = *dom;
@@ -1509,6 +1608,8 @@ struct Strip {
     ststhip_exchange_fn exchange = nullptr;
     void *exchange_ctx = nullptr;
     std::uint64_t total_rows = 0, width = 0, row_begin = 0, row_end = 0, g_max = 0, local_rows = 0;
+    std::uint64_t ghost = 0;   // ghost rows the buffers hold above and below the owned rows: g_max * exchange_every
+    int exchange_every = 1;    // launches per ghost exchange (fixed at creation: it sizes the buffers)
     std::int64_t row_origin = 0;
     unsigned n_planes = 0;
     std::size_t elem[16] = {0};
@@ -1534,7 +1635,7 @@ int strip_exchange(Strip &st, int set, std::uint64_t g) {
     const void *send_up[16], *send_down[16];
     void *recv_up[16], *recv_down[16];
     std::size_t row_bytes[16];
-    const std::uint64_t o_start = st.g_max, o_stop = st.g_max + (st.row_end - st.row_begin);
+    const std::uint64_t o_start = st.ghost, o_stop = st.ghost + (st.row_end - st.row_begin);
     for (unsigned p = 0; p < st.n_planes; p++) {
         row_bytes[p] = std::size_t(st.dom.pitch) * st.elem[p];
         unsigned char *base = static_cast<unsigned char *>(st.planes[set][p]);
@@ -1562,18 +1663,21 @@ int finish_strip(Strip *st, const ststhip_domain *dom, ststhip_strip *strip) {
     }
     st->n_planes = d.n_planes;
     st->g_max = std::uint64_t(d.max_generations) * d.halo_depth_per_generation;
+    st->exchange_every = st->n_ranks > 1 ? std::min(std::max(opt().exchange_every, 1), 16) : 1;
+    st->ghost = st->g_max * std::uint64_t(st->exchange_every);
     std::uint64_t thinnest = st->total_rows;
     for (int r = 0; r < st->n_ranks; r++) {
         std::uint64_t a, b;
         strip_bounds(st->total_rows, st->n_ranks, r, a, b);
         thinnest = std::min(thinnest, b - a);
     }
-    if (st->n_ranks > 1 && thinnest < 2 * st->g_max) {
+    if (st->n_ranks > 1 && thinnest < 2 * st->ghost) {
         delete st;
-        return fail(STSTHIP_ERR_INVALID, "strips are thinner than two halo depths: use fewer ranks or a larger grid");
+        return fail(STSTHIP_ERR_INVALID, "strips are thinner than two ghost depths: use fewer ranks, a larger grid or a "
+                                         "smaller STSTHIP_EXCHANGE_EVERY");
     }
-    st->row_origin = std::int64_t(st->row_begin) - std::int64_t(st->g_max);
-    st->local_rows = (st->row_end - st->row_begin) + 2 * st->g_max;
+    st->row_origin = std::int64_t(st->row_begin) - std::int64_t(st->ghost);
+    st->local_rows = (st->row_end - st->row_begin) + 2 * st->ghost;
     st->dom = *dom; // width and pitch possibly in words
     st->dom.row_origin = st->row_origin;
     st->dom.local_rows = st->local_rows;
@@ -1583,7 +1687,7 @@ int finish_strip(Strip *st, const ststhip_domain *dom, ststhip_strip *strip) {
     // sub-strips it cost 8-30 % (streams of one priority share few hardware queues, and a band waiting for its events
     // holds up whatever sits behind it in the same queue: profiles/r02_thin_strips.txt section 7)
     if (err == hipSuccess)
-        err = stencil::hip::internal::env_int("STSTHIP_COMM_STREAM_PRIORITY", 0)
+        err = opt().comm_stream_priority
                   ? create_band_stream(&st->comm_stream)
                   : hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking);
     for (int set = 0; set < 2 && err == hipSuccess && rc == STSTHIP_OK; set++)
@@ -1721,7 +1825,7 @@ int ststhip_strip_plane(ststhip_strip strip, unsigned plane, void **owned_rows, 
     if (!st || plane >= st->n_planes || !owned_rows)
         return fail(STSTHIP_ERR_INVALID, "bad plane index or null argument");
     const std::size_t bytes = std::size_t(st->dom.pitch) * st->elem[plane];
-    *owned_rows = static_cast<unsigned char *>(st->planes[st->current][plane]) + st->g_max * bytes;
+    *owned_rows = static_cast<unsigned char *>(st->planes[st->current][plane]) + st->ghost * bytes;
     if (row_bytes)
         *row_bytes = bytes;
     return STSTHIP_OK;
@@ -1767,6 +1871,145 @@ int ststhip_strip_warm_up(ststhip_strip strip) {
     return STSTHIP_OK;
 }
 
+// ststhip_strip_advance with STSTHIP_EXCHANGE_EVERY = m > 1: the launches of a call go in groups of m with ONE ghost
+// exchange per group.  Before a group the neighbours exchange G = sum of the group's halo depths g_j ghost rows; launch
+// j of the group then produces its owned rows widened by E_j = g_(j+1) + ... + g_(m-1) rows on every side that has a
+// neighbour (both neighbours compute those rows: g*m*(m-1) redundant rows per group, 2 % of a 2048-row strip at m = 4,
+// T = 12), so the next launch finds its halo without a message.  Only the LAST launch of a group is split: its top
+// and bottom G' rows (G' = ghost depth of the next group) run as one band launch on the highest-priority stream, the
+// exchange for the next group follows them on the comm stream, and the interior runs beside both.  Per group: one
+// band launch and one exchange instead of m of each -- for thin strips, where the band -> exchange -> band chain of
+// every launch is as long as the interior.  One sub-strip per rank.
+namespace {
+int strip_advance_grouped(Strip *st, std::uint64_t iteration_offset, std::uint64_t n_generations, int blocking,
+                          std::vector<std::uint32_t> const &depths) {
+    const ststhip_sweep_desc &d = st->resolved.desc;
+    const std::uint64_t hpg = d.halo_depth_per_generation;
+    const std::uint64_t a = st->row_begin, b = st->row_end;
+    const std::size_t m = std::size_t(st->exchange_every);
+    int rc = STSTHIP_OK;
+    EventPool events;
+    auto ordered = [&](hipError_t err, const char *what) {
+        if (err != hipSuccess && rc == STSTHIP_OK)
+            rc = hip_fail(err, what);
+    };
+    auto record = [&](hipStream_t on) {
+        hipEvent_t ev = events.take();
+        if (!ev)
+            ordered(hipErrorUnknown, "hipEventCreateWithFlags");
+        else
+            ordered(hipEventRecord(ev, on), "hipEventRecord");
+        return ev;
+    };
+    auto wait = [&](hipStream_t who, hipEvent_t ev) {
+        if (ev)
+            ordered(hipStreamWaitEvent(who, ev, 0), "hipStreamWaitEvent");
+    };
+    if (st->band.empty()) {
+        hipStream_t lane;
+        if (create_band_stream(&lane) != hipSuccess)
+            return hip_fail(hipErrorUnknown, "hipStreamCreateWithPriority");
+        st->band.push_back(lane);
+    }
+    hipStream_t band = st->band[0];
+    const bool pretend = opt().pretend_neighbours != 0;
+    const bool has_up = st->rank > 0 || pretend, has_down = st->rank + 1 < st->n_ranks || pretend;
+    g_launch_concurrency = 1;
+    void *tdv_table = nullptr;
+    if (d.tdv_size > 0 && d.fill_tdv) {
+        const std::size_t bytes = std::size_t(d.tdv_size) * n_generations;
+        rc = ststhip_malloc_async(&tdv_table, bytes, st->compute);
+        if (rc == STSTHIP_OK) {
+            std::vector<unsigned char> values(bytes);
+            d.fill_tdv(st->resolved.ctx, iteration_offset, n_generations, values.data());
+            ordered(hipMemcpyAsync(tdv_table, values.data(), bytes, hipMemcpyHostToDevice, st->compute), "hipMemcpyAsync");
+            ordered(hipStreamSynchronize(st->compute), "hipStreamSynchronize"); // `values` is pageable and goes out of scope
+            g_tdv_table = tdv_table;
+            g_tdv_first = iteration_offset;
+            g_tdv_count = n_generations;
+            g_tdv_size = d.tdv_size;
+        }
+    }
+    auto group_depth = [&](std::size_t first) {
+        std::uint64_t sum = 0;
+        for (std::size_t i = first; i < std::min(first + m, depths.size()); i++)
+            sum += depths[i] * hpg;
+        return sum;
+    };
+    hipEvent_t begin = record(st->compute);
+    wait(st->comm_stream, begin);
+    wait(band, begin);
+    hipEvent_t ghosts_ready = nullptr, bands_done = nullptr;
+    if (st->n_ranks > 1 && rc == STSTHIP_OK) {
+        rc = strip_exchange(*st, st->current, group_depth(0));
+        ghosts_ready = record(st->comm_stream);
+    }
+    std::uint64_t iteration = iteration_offset;
+    for (std::size_t first = 0; first < depths.size() && rc == STSTHIP_OK; first += m) {
+        const std::size_t last = std::min(first + m, depths.size()) - 1;
+        // the group's first launch reads the ghost rows of this group and everything the previous group left
+        wait(st->compute, ghosts_ready);
+        wait(st->compute, bands_done);
+        std::uint64_t widen = group_depth(first); // E_(j-1): how far beyond the owned rows the launch's input is valid
+        for (std::size_t i = first; i <= last && rc == STSTHIP_OK; i++) {
+            const std::uint32_t depth = depths[i];
+            widen -= depth * hpg; // E_j
+            const void *const *src = const_cast<const void *const *>(st->planes[st->current]);
+            void *const *dst = st->planes[st->current ^ 1];
+            const std::uint64_t lo = has_up ? a - std::min(widen, a) : a;
+            const std::uint64_t hi = has_down ? std::min(b + widen, st->total_rows) : b;
+            auto sweep = [&](std::uint64_t r0, std::uint64_t r1, hipStream_t on) {
+                if (r0 < r1 && rc == STSTHIP_OK) {
+                    rc = st->resolved.trampoline(st->resolved.ctx, &st->dom, src, dst, r0, r1, iteration, depth, on);
+                    st->n_launches++;
+                }
+            };
+            const bool feeds_exchange = i == last && last + 1 < depths.size() && (has_up || has_down);
+            if (feeds_exchange) {
+                const std::uint64_t next = group_depth(last + 1);
+                const std::uint64_t top_end = has_up ? a + next : a;
+                const std::uint64_t bot_begin = has_down ? b - next : b;
+                // the bands read what the previous launch (compute stream) or, in a group of one, the exchange left
+                wait(band, record(st->compute));
+                wait(band, ghosts_ready);
+                if (a < top_end && bot_begin < b && top_end < bot_begin) {
+                    g_row_hole_begin = top_end;
+                    g_row_hole_end = bot_begin;
+                    sweep(a, b, band);
+                    g_row_hole_begin = g_row_hole_end = 0;
+                } else {
+                    sweep(a, top_end, band);
+                    sweep(bot_begin, b, band);
+                }
+                bands_done = record(band);
+                if (st->n_ranks > 1 && rc == STSTHIP_OK) {
+                    wait(st->comm_stream, bands_done);
+                    rc = strip_exchange(*st, st->current ^ 1, next);
+                    ghosts_ready = record(st->comm_stream);
+                }
+                sweep(top_end, bot_begin, st->compute);
+            } else {
+                sweep(lo, hi, st->compute);
+            }
+            st->current ^= 1;
+            iteration += depth;
+        }
+    }
+    g_tdv_table = nullptr;
+    g_tdv_count = 0;
+    wait(st->compute, record(band));
+    wait(st->compute, record(st->comm_stream));
+    if (rc == STSTHIP_OK && blocking) {
+        hipError_t err = hipStreamSynchronize(st->compute);
+        if (err != hipSuccess)
+            rc = hip_fail(err, "hipStreamSynchronize");
+    }
+    if (tdv_table)
+        ststhip_free_async(tdv_table, st->compute);
+    return rc;
+}
+} // namespace
+
 // One call = n_generations generations of the whole distributed grid.  Per pass p (buffer sets ping-pong, g = halo
 // rows of the pass):
 //     sub-strip v (own stream): wait(bands of v-1, v+1 of pass p-1; outermost: the ghost rows of pass p)
@@ -1783,21 +2026,22 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     if (depths.empty())
         return STSTHIP_OK;
     st->resolved.set_run(iteration_offset, n_generations);
+    if (st->exchange_every > 1)
+        return strip_advance_grouped(st, iteration_offset, n_generations, blocking, depths);
     const std::uint64_t hpg = d.halo_depth_per_generation;
     const std::uint64_t a = st->row_begin, b = st->row_end;
     int rc = STSTHIP_OK;
-    std::vector<hipEvent_t> events;
+    EventPool events;
     auto ordered = [&](hipError_t err, const char *what) {
         if (err != hipSuccess && rc == STSTHIP_OK)
             rc = hip_fail(err, what);
     };
     auto record = [&](hipStream_t on) {
-        hipEvent_t ev = nullptr;
-        ordered(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreateWithFlags");
-        if (ev) {
+        hipEvent_t ev = events.take();
+        if (!ev)
+            ordered(hipErrorUnknown, "hipEventCreateWithFlags");
+        else
             ordered(hipEventRecord(ev, on), "hipEventRecord");
-            events.push_back(ev);
-        }
         return ev;
     };
     auto wait = [&](hipStream_t who, hipEvent_t ev) {
@@ -1806,7 +2050,8 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     };
 
     // sub-strips of the owned rows, the rule of the single-GPU pass driver
-    const bool neighbours = st->n_ranks > 1 || stencil::hip::internal::env_int("STSTHIP_STRIP_DEBUG_BANDS", 0) != 0;
+    const bool pretend = opt().pretend_neighbours != 0; // EXPERIMENTS builds only, 0 in the product library
+    const bool neighbours = st->n_ranks > 1 || pretend;
     int n_sub = suggest_row_strips(b - a, st->dom.global_width, d.strip_width, st->g_max, depths.size(), neighbours);
     n_sub = std::min(n_sub, 2);
     while (n_sub > 1 && (b - a) < std::uint64_t(n_sub) * 2 * std::max<std::uint64_t>(st->g_max, 1))
@@ -1814,7 +2059,7 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     std::vector<std::uint64_t> bound(n_sub + 1);
     for (int v = 0; v <= n_sub; v++)
         bound[v] = a + (b - a) * std::uint64_t(v) / std::uint64_t(n_sub);
-    if (n_sub == 2 && !stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1))
+    if (n_sub == 2 && !opt().bands_beside_interior)
         bound[1] = a + (b - a) * 2 / 5; // bands in front of the interiors: unequal strips drift out of phase
     while (int(st->side.size()) < n_sub - 1) {
         hipStream_t lane;
@@ -1830,9 +2075,9 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     // is a dependent chain of 3g row steps per wave: 55-120 us beside a busy interior, and the two bands of a
     // sub-strip follow each other in one stream.  STSTHIP_BANDS_APART=1 gives the top and the bottom band a stream
     // each: measured 5-25 % slower (more streams than hardware queues; profiles/r02_thin_strips.txt), so it is off.
-    const bool bands_beside = stencil::hip::internal::env_int("STSTHIP_BANDS_BESIDE_INTERIOR", 1) != 0;
-    const bool bands_apart = bands_beside && stencil::hip::internal::env_int("STSTHIP_BANDS_APART", 0) != 0;
-    const bool bands_one_launch = stencil::hip::internal::env_int("STSTHIP_BANDS_ONE_LAUNCH", 1) != 0;
+    const bool bands_beside = opt().bands_beside_interior != 0;
+    const bool bands_apart = bands_beside && opt().bands_apart != 0;
+    const bool bands_one_launch = opt().bands_one_launch != 0;
     // (only as many as are used: streams are dealt onto a few hardware queues in creation order, idle ones included)
     const int n_band_streams = bands_apart ? 2 * n_sub : n_sub;
     while (bands_beside && int(st->band.size()) < n_band_streams) {
@@ -1841,9 +2086,6 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
             return hip_fail(hipErrorUnknown, "hipStreamCreateWithPriority");
         st->band.push_back(lane);
     }
-    // STSTHIP_STRIP_DEBUG_BANDS=1 (timing experiments on one GPU only, results are WRONG at the strip's ends): launch
-    // the bands a strip with neighbours on both sides launches, without the exchange
-    const bool pretend = stencil::hip::internal::env_int("STSTHIP_STRIP_DEBUG_BANDS", 0) != 0;
     const bool has_up = st->rank > 0 || pretend, has_down = st->rank + 1 < st->n_ranks || pretend;
     g_launch_concurrency = n_sub;
 
@@ -1857,6 +2099,7 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
             std::vector<unsigned char> values(bytes);
             d.fill_tdv(st->resolved.ctx, iteration_offset, n_generations, values.data());
             ordered(hipMemcpyAsync(tdv_table, values.data(), bytes, hipMemcpyHostToDevice, st->compute), "hipMemcpyAsync");
+            ordered(hipStreamSynchronize(st->compute), "hipStreamSynchronize"); // `values` is pageable and goes out of scope
             g_tdv_table = tdv_table;
             g_tdv_first = iteration_offset;
             g_tdv_count = n_generations;
@@ -1976,9 +2219,7 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     }
     if (tdv_table)
         ststhip_free_async(tdv_table, st->compute); // every stream has been joined into the compute stream above
-    for (hipEvent_t ev : events)
-        (void)hipEventDestroy(ev); // released once they have completed
-    return rc;
+    return rc; // the events go back to the pool (EventPool): a recorded event may be re-recorded once it is no longer waited for
 }
 
 } // extern "C"

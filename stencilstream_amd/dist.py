@@ -307,3 +307,41 @@ class _NullContext:
 
     def __exit__(self, *exc):
         return False
+
+
+def host_exchange_callback(rank, world):
+    """An `exchange` callable for capi.Strip (contract of ststhip_comm_exchange_rows) that stages the ghost rows
+    through host memory over the default process group (gloo): for hosts whose ranks RCCL cannot join -- several
+    processes sharing one GPU (tests/test_strip_native_gpu.py, `bench.py --debug-host-exchange`)."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from . import capi
+
+    lib = capi.load()
+
+    def exchange(n_planes, send_up, send_down, recv_up, recv_down, row_bytes, n_rows, stream):
+        capi.check(lib.ststhip_stream_synchronize(C.c_void_p(stream)), "sync")
+        ops, landing = [], []
+        for p in range(n_planes):
+            n = row_bytes[p] * n_rows
+            for peer, send, recv in ((rank - 1, send_up[p], recv_up[p]), (rank + 1, send_down[p], recv_down[p])):
+                if peer < 0 or peer >= world:
+                    continue
+                out = torch.empty(n, dtype=torch.uint8)
+                capi.check(lib.ststhip_memcpy_d2h(C.c_void_p(out.data_ptr()), C.c_void_p(send), n, C.c_void_p(stream)), "d2h")
+                inc = torch.empty(n, dtype=torch.uint8)
+                landing.append((recv, inc, n))
+                ops.append((peer, out, inc))
+        capi.check(lib.ststhip_stream_synchronize(C.c_void_p(stream)), "sync")
+        reqs = dist.batch_isend_irecv([x for peer, out, inc in ops
+                                       for x in (dist.P2POp(dist.isend, out, peer), dist.P2POp(dist.irecv, inc, peer))])
+        for r in reqs:
+            r.wait()
+        for recv, inc, n in landing:
+            capi.check(lib.ststhip_memcpy_h2d(C.c_void_p(recv), C.c_void_p(inc.data_ptr()), n, C.c_void_p(stream)), "h2d")
+        capi.check(lib.ststhip_stream_synchronize(C.c_void_p(stream)), "sync")
+
+    return exchange

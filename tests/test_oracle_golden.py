@@ -132,6 +132,35 @@ def test_hotspot_against_rodinia_openmp(oracle, tmp_path):
     assert np.abs(out.astype(np.float64) - ref).max() <= 2 * KNOWN["hotspot_64"]["rodinia_openmp_max_abs_diff"]
 
 
+def load_hotspot_512(oracle):
+    import gzip
+
+    t = np.loadtxt(gzip.open(os.path.join(GOLDEN, "hotspot_temp_512.txt.gz"), "rt"), dtype=np.float32).reshape(512, 512)
+    p = np.loadtxt(gzip.open(os.path.join(GOLDEN, "hotspot_power_512.txt.gz"), "rt"), dtype=np.float32).reshape(512, 512)
+    cells = np.zeros((512, 512), dtype=oracle.HOTSPOT_CELL)
+    cells["temp"], cells["power"] = t, p
+    return cells
+
+
+def test_hotspot_512_against_rodinia_fixture(oracle):
+    """The reference's larger HotSpot data set (examples/hotspot/data/{temp,power}_512) against the committed output
+    of Rodinia's OpenMP HotSpot built unchanged from the reference tree (tests/golden/make_hotspot_512_fixture.py):
+    a second reference-compiled pin of the oracle's HotSpot restatement.  The data set sits near its steady state:
+    2000 iterations move every temperature by 0.061 K.  Rodinia is another program (other operation order, six
+    printed digits): the two agree to 0.0003 K on average -- half a per cent of the movement --, to 0.002 K on more
+    than 99.8 % of the cells; the rest are a patch at the top edge where the update of the reference's expression
+    order rounds to no change in fp32 and Rodinia's order does not."""
+    fixture = np.load(os.path.join(GOLDEN, "hotspot_512_rodinia_2000.npz"))
+    cells = load_hotspot_512(oracle)
+    out = oracle.hotspot(oracle.hotspot_params(512, 512), cells, int(fixture["iterations"]), n_threads=8)["temp"]
+    diff = np.abs(out.astype(np.float64) - fixture["temp"].astype(np.float64))
+    moved = np.abs(out.astype(np.float64) - cells["temp"].astype(np.float64))
+    assert np.median(moved) > 0.05  # the iterations changed the field by far more than the agreement asserted below
+    assert diff.mean() <= 0.0006, diff.mean()
+    assert (diff <= 0.002).mean() >= 0.998, (diff <= 0.002).mean()
+    assert diff.max() <= 0.07, diff.max()
+
+
 def test_fdtd_oracle_against_unchanged_reference_functor(oracle):
     """Pins the oracle's FDTD restatement (transition function, TDV, and the example's set-up
     arithmetic restated in tests/fdtd_harness.py): tests/golden/fdtd/*.csv were written by the

@@ -945,36 +945,6 @@ def test_hotspot_fp64_bit_exact(gpu, oracle, split):
     assert np.abs(want["temp"] - cells["temp"]).max() > 0
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (5, 700), (300, 257), (700, 1100), (1500, 2300)], ids=str)
-def test_cooperative_strips_bit_exact(gpu, oracle, shape):
-    """Sweep<..., COOP = true>: the waves of a workgroup exchange their edge columns through LDS.  Jacobi5General
-    (one word, K = 4) and HotSpot on planes (two words, K = 1, `power` stores skipped from the third launch on):
-    grids narrower than one workgroup tile, ragged widths, several workgroup columns and row chunks; the launch
-    depths 8 + 4 + 1 and 8 + 8 + 8 + 2; bit for bit against the oracle."""
-    from stencilstream_amd import capi, update as U
-
-    rng = np.random.default_rng(shape[0] * 7 + shape[1])
-    H, W = shape
-    grid = rng.random(shape, dtype=np.float32)
-    coef = [0.1, 0.2, 0.3, 0.25, 0.15]
-    tf = U.TransitionFunction("jacobi5general_coop", U.jacobi("Jacobi5General", coef).params, np.dtype("<f4"))
-    assert capi.app_info("jacobi5general_coop").cooperative == 1
-    for n in (13, 26):
-        got = run_hip(tf, grid, n, halo=np.float32(0.125))
-        want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=0.125, n_threads=8)
-        assert np.array_equal(bits(got), bits(want)), f"jacobi n={n}"
-
-    cells = np.zeros(shape, dtype=U.HOTSPOT_CELL)
-    cells["temp"] = 320 + 10 * rng.random(shape, dtype=np.float32)
-    cells["power"] = rng.random(shape, dtype=np.float32) * 0.01
-    p = oracle.hotspot_params(*shape)
-    tf = U.TransitionFunction("hotspot_coop", capi.HotspotParams(p.Rx_1, p.Ry_1, p.Rz_1, p.Cap_1), U.HOTSPOT_CELL)
-    for n in (3, 26):
-        got = run_hip(tf, cells, n)
-        want = oracle.hotspot(p, cells, n, n_threads=8)
-        assert np.array_equal(bits(got), bits(want)), f"hotspot n={n}"
-
-
 @pytest.mark.parametrize("shape", [(1, 1), (2, 9), (64, 64), (130, 517), (700, 300)], ids=str)
 def test_jacobi25_radius2_bit_exact(gpu, oracle, shape):
     """The dense 5 x 5 Jacobi of radius 2 ("jacobi25general", an extra: SURVEY 8(f)4): two-cell halos in rows and
@@ -1070,23 +1040,6 @@ def test_pool_hands_blocks_over_in_stream_order(gpu):
     capi.check(lib.ststhip_stream_destroy(s2), "stream")
 
 
-@pytest.mark.parametrize("shape", [(300, 257), (1200, 700), (4000, 1500)], ids=str)
-def test_persistent_waves_bit_exact(gpu, oracle, shape):
-    """sweep_kernel<..., PERSISTENT>: waves claim 32-row chunks and continue into the chunk below without re-warming
-    their pipeline ("jacobi5general_persistent"; launches of fewer than 256 rows use the chunked kernel): grids with a
-    few and with many chunks per strip, the launch depths 8 + 4 + 1 and 8 + 8 + 8 + 2, edge and interior code paths."""
-    from stencilstream_amd import capi, update as U
-
-    rng = np.random.default_rng(shape[0] + shape[1])
-    grid = rng.random(shape, dtype=np.float32)
-    coef = [0.1, 0.2, 0.3, 0.25, 0.15]
-    tf = U.TransitionFunction("jacobi5general_persistent", U.jacobi("Jacobi5General", coef).params, np.dtype("<f4"))
-    for n in (13, 26):
-        got = run_hip(tf, grid, n, halo=np.float32(0.125))
-        want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=0.125, n_threads=8)
-        assert np.array_equal(bits(got), bits(want)), f"n={n}"
-
-
 @pytest.mark.parametrize("strips", ["2", "3", "4"])
 def test_row_strips_with_bands_beside_interiors_full_size(gpu, monkeypatch, strips):
     """The pass driver's row strips at BASELINE size with ragged launch depths (40 = 12 + 12 + 12 + 3 + 1 and
@@ -1121,3 +1074,130 @@ def test_row_strips_with_bands_beside_interiors_full_size(gpu, monkeypatch, stri
             capi.app_run("jacobi5general", p, np.float32(0).tobytes(), dom, [src.data_ptr()], [got.data_ptr()], 0, 40,
                          blocking=True, stream=s.cuda_stream)
             assert torch.equal(got, want)
+
+
+def test_staged_sweeps_describe_themselves(gpu):
+    """The staged sweep is the default of the precompiled applications (Sweep.hpp: the waves of a workgroup share one
+    column strip as a pipeline over the levels); the independent-wave shapes stay registered as A/B baselines."""
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    for app, stages in (("jacobi5uniform", 4), ("jacobi5general", 4), ("hotspot", 4), ("hotspot_aos", 4),
+                        ("fdtd_coef_grouped", 4), ("fdtd_coef_aos", 4), ("conway_packed", 4),
+                        ("jacobi5general_independent", 1), ("hotspot_independent", 1)):
+        assert capi.app_info(app).stages == stages, app
+    # a wave's share of its workgroup's strip is what the drivers count waves with
+    info = capi.app_info("jacobi5uniform")
+    assert info.strip_width == (64 * info.cells_per_lane - 2 * 12) // 4
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 70), (37, 257), (300, 700), (1100, 2300)], ids=str)
+def test_staged_depths_and_ragged_batches(gpu, oracle, shape):
+    """Generation counts that use every compiled depth of the staged kernels (12 + 6 + 3 + 1 with four, three, three
+    and one stage; 8 + 4 + 2 + 1 with four, four, two, one) on grids whose row counts are not multiples of the batch
+    length, narrower than one strip, and with halo values that differ from the cells: uniform-coefficient Jacobi,
+    general Jacobi, HotSpot on planes and as AoS (two cells per lane), against the oracle bit for bit."""
+    from stencilstream_amd import update as U
+
+    rng = np.random.default_rng(shape[0] * 31 + shape[1])
+    grid = rng.random(shape, dtype=np.float32)
+    for coef, halo in (([0.2] * 5, 0.0), ([0.1, 0.2, 0.3, 0.25, 0.15], 0.375)):
+        for n in (22, 15):
+            got = run_hip(U.jacobi("Jacobi5General", coef), grid, n, halo=np.float32(halo))
+            want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=halo, n_threads=8)
+            assert np.array_equal(bits(got), bits(want)), f"jacobi {coef[0]} n={n}"
+    cells = np.zeros(shape, dtype=U.HOTSPOT_CELL)
+    cells["temp"] = 320 + 10 * rng.random(shape, dtype=np.float32)
+    cells["power"] = rng.random(shape, dtype=np.float32) * 0.01
+    p = oracle.hotspot_params(*shape)
+    for split in (True, False):
+        for n in (22, 31):
+            got = run_hip(U.hotspot(p.Rx_1, p.Ry_1, p.Rz_1, p.Cap_1, split_cell_structure=split), cells, n)
+            want = oracle.hotspot(p, cells, n, n_threads=8)
+            assert np.array_equal(bits(got), bits(want)), f"hotspot split={split} n={n}"
+
+
+def test_staged_sweep_race_screen(gpu):
+    """The stages of a workgroup hand rows to each other through LDS between barriers; a missing wait there shows as
+    a few wrong cells in one launch of several hundred (it did, once: Sweep.hpp keeps an explicit s_waitcnt in front
+    of the barrier since).  Repeated long runs at full size -- thousands of workgroups per launch, hundreds of
+    launches -- must equal the independent-wave kernels' results bit for bit, every time."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    s = torch.cuda.Stream()
+    H = W = 8192
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    temp = 320 + 10 * torch.rand(H, W, device=gpu, generator=gen)
+    power = 0.01 * torch.rand(H, W, device=gpu, generator=gen)
+    dom = capi.Domain(H, W, 0, H, W)
+    p = oracle_free_hotspot_params(H)
+
+    def run(app, planes, n):
+        out = [torch.zeros_like(t) for t in planes]
+        torch.cuda.synchronize()
+        capi.app_run(app, p, bytes(8), dom, [t.data_ptr() for t in planes], [t.data_ptr() for t in out], 0, n,
+                     blocking=True, stream=s.cuda_stream)
+        return out
+
+    want = run("hotspot_independent", [temp, power], 240)
+    for trial in range(12):
+        got = run("hotspot", [temp, power], 240)
+        assert torch.equal(got[0].view(torch.int32), want[0].view(torch.int32)), f"hotspot, trial {trial}"
+    del want, got
+    q = capi.JacobiParams()
+    for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
+        q.coef[i] = c
+    want = run_jacobi(capi, s, "jacobi5general_independent", q, temp, 240)
+    for trial in range(12):
+        got = run_jacobi(capi, s, "jacobi5general", q, temp, 240)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"jacobi, trial {trial}"
+
+
+def run_jacobi(capi, stream, app, params, grid, n):
+    import torch
+
+    out = torch.zeros_like(grid)
+    torch.cuda.synchronize()
+    H, W = grid.shape
+    capi.app_run(app, params, np.float32(0).tobytes(), capi.Domain(H, W, 0, H, W), [grid.data_ptr()], [out.data_ptr()],
+                 0, n, blocking=True, stream=stream.cuda_stream)
+    return out
+
+
+def oracle_free_hotspot_params(n):
+    """examples/hotspot/hotspot.cpp:281-295 with numpy's float32 / float64 (the binding's parameter block)."""
+    from stencilstream_amd import capi
+
+    f32, f64 = np.float32, np.float64
+    t_chip, chip = f32(0.0005), f32(0.016)
+    gh, gw = f32(chip / f32(n)), f32(chip / f32(n))
+    cap = f32(f64(0.5) * f64(1.75e6) * f64(t_chip) * f64(gh) * f64(gw))
+    rx = f32(f64(gw) / (f64(2.0) * 100 * f64(t_chip) * f64(gh)))
+    ry = f32(f64(gh) / (f64(2.0) * 100 * f64(t_chip) * f64(gw)))
+    rz = f32(t_chip / f32(f32(f32(100) * gh) * gw))
+    max_slope = f32(f64(3.0e6) / (f64(0.5) * f64(t_chip) * f64(1.75e6)))
+    step = f32(f64(0.001) / f64(max_slope) / f64(1000.0))
+    return capi.HotspotParams(float(f32(1) / rx), float(f32(1) / ry), float(f32(1) / rz), float(step / cap))
+
+
+@pytest.mark.parametrize("split", [True, False], ids=["planes", "aos"])
+def test_hotspot_512_reference_data_bit_exact(gpu, oracle, split):
+    """The reference's 512 x 512 HotSpot data set (tests/golden/hotspot_{temp,power}_512.txt.gz; the oracle is pinned on
+    it by Rodinia's own program, tests/test_oracle_golden.py): HIP against the oracle, bit for bit, 2000 iterations as
+    in the fixture and 37 (ragged launch depths)."""
+    import gzip
+
+    from stencilstream_amd import update as U
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cells = np.zeros((512, 512), dtype=U.HOTSPOT_CELL)
+    cells["temp"] = np.loadtxt(gzip.open(os.path.join(golden, "hotspot_temp_512.txt.gz"), "rt"), dtype=np.float32).reshape(512, 512)
+    cells["power"] = np.loadtxt(gzip.open(os.path.join(golden, "hotspot_power_512.txt.gz"), "rt"), dtype=np.float32).reshape(512, 512)
+    p = oracle.hotspot_params(512, 512)
+    for n in (2000, 37):
+        got = run_hip(U.hotspot(p.Rx_1, p.Ry_1, p.Rz_1, p.Cap_1, split_cell_structure=split), cells, n)
+        want = oracle.hotspot(p, cells, n, n_threads=8)
+        assert np.array_equal(bits(got), bits(want)), f"n={n}"

@@ -59,7 +59,9 @@ def main():
     which = sys.argv[1:] or ["jacobi", "hotspot", "hotspot_aos", "hotspot_f64", "hotspot_f64_aos", "fdtd", "fdtd_aos",
                              "fdtd_grouped", "conway"]
     if which == ["experiments"]:
-        which = ["hotspot", "fdtd", "fdtd_aos", "conway"] + [a for a in capi.list_apps() if a.startswith(("x_hs_", "x_fd_", "x_cw_"))]
+        which = sorted(a for a in capi.list_apps() if a.startswith(("x_hs_", "x_fd_", "x_cw_")))
+        if os.environ.get("AB_ONLY"):
+            which = [a for a in which if any(a.startswith(p) for p in os.environ["AB_ONLY"].split(","))]
     capi.init(0)
     dev = "cuda"
     stream = torch.cuda.Stream()
@@ -72,8 +74,8 @@ def main():
                 p.coef[i] = 0.2
             halo = np.float32(0).tobytes()
             pa, pb = [torch.rand(H, W, device=dev)], [torch.empty(H, W, device=dev)]
-        elif name in ("jacobi_general", "jacobi_general_persistent"):
-            app, (H, W), gens = ("jacobi5general" if name == "jacobi_general" else "jacobi5general_persistent"), dims(16384, 16384), 240
+        elif name in ("jacobi_general", "jacobi_general_independent"):
+            app, (H, W), gens = ("jacobi5general" if name == "jacobi_general" else "jacobi5general_independent"), dims(16384, 16384), 240
             p = capi.JacobiParams()
             for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
                 p.coef[i] = c
@@ -146,17 +148,28 @@ def main():
                 # packed Game of Life: a 16384^2 grid of cells = 16384 x 4096 words of four cells
                 H, W, gens, p, fill = 16384, 4096, 192, capi.NoParams(), None
             halo = bytes(meta.cell_size)
+            # seeded random fields (constants where the application has constants): every cell evolves differently,
+            # so the checksum below tells two shapes' results apart
+            gen = torch.Generator(device=dev).manual_seed(1234)
+
+            def field(i, v):
+                if name.startswith("x_hs_"):
+                    return (320.0 + 10.0 * torch.rand(H, W, device=dev, generator=gen)) if i == 0 else \
+                        0.01 * torch.rand(H, W, device=dev, generator=gen)
+                if i < 4:
+                    return 1e-3 * torch.rand(H, W, device=dev, generator=gen)
+                return torch.full((H, W), v, device=dev)
+
             if fill is None:
-                pa = [(torch.rand(H, 4 * W, device=dev) < 0.35).to(torch.uint8).view(torch.int32)]
+                pa = [(torch.rand(H, 4 * W, device=dev, generator=gen) < 0.35).to(torch.uint8).view(torch.int32)]
+            elif "_grp_" in name:  # FdtdGrouped: two planes of 16-byte halves {ex, ey, hz, hz_sum} / {ca, cb, da, db}
+                pa = [torch.stack([field(i, fill[i]) for i in range(4 * h, 4 * h + 4)], dim=-1).contiguous() for h in range(2)]
             elif meta.n_planes == 1:
-                cells = torch.empty(H, W, len(fill), device=dev)
-                for i, v in enumerate(fill):
-                    cells[..., i] = v
-                assert cells.element_size() * len(fill) == meta.cell_size
-                pa = [cells]
+                pa = [torch.stack([field(i, v) for i, v in enumerate(fill)], dim=-1).contiguous()]
+                assert pa[0].element_size() * len(fill) == meta.cell_size
             else:
                 assert meta.n_planes == len(fill) and all(meta.plane_elem_size[i] == 4 for i in range(len(fill)))
-                pa = [torch.full((H, W), v, device=dev) for v in fill]
+                pa = [field(i, v) for i, v in enumerate(fill)]
             pb = [torch.empty_like(t) for t in pa]
         else:
             raise SystemExit(f"unknown app {name}")
@@ -168,7 +181,10 @@ def main():
             bytes_per_update = 2  # one byte per cell of the game, four cells per word
         cells_per_elem = 4 if name.startswith("x_cw_") else 1
         gcells = H * W * cells_per_elem * gens / best / 1e9
+        # results of the same function, layout and generation count must agree bit for bit whatever the shape
+        checksum = sum(int(t.view(torch.int32).to(torch.int64).sum().item()) for t in pb) & 0xFFFFFFFFFFFF
         line = {"app": app, "grid": [H, W], "generations": gens, "Gcell_updates_per_s": round(gcells, 1),
+                "stages": int(info.stages), "K": int(info.cells_per_lane), "T": int(info.max_generations), "checksum": checksum,
                 "ms_per_launch": round(best / launches * 1e3, 4), "generations_per_launch": gens / launches,
                 "algorithmic_bytes_per_cell_update": bytes_per_update,
                 "algorithmic_GBps": round(gcells * bytes_per_update, 1),
