@@ -644,6 +644,7 @@ def main():
             out["verification"] = strips_report
         if world == 1 and not args.strip_domain:
             launches_per_step = int(last["info"].n_launches)
+            out["launches_per_step"] = launches_per_step
             if not args.no_verify:
                 ok, report = verify_timed(torch, capi, p, halo, dom, src, dst, gens, stream, total_rows, W)
                 out["verified"] = bool(ok)

@@ -167,7 +167,7 @@ typedef struct {
     int32_t jacobi_fastpath, conway_fastpath;
     int32_t prepare_streams;       /* create and first-use the pass driver's streams at ststhip_init      */
     int32_t host_cache_mib;        /* free pinned host blocks kept for reuse                              */
-    int32_t pretend_neighbours;    /* EXPERIMENTS builds only (timing studies on one GPU); 0 otherwise    */
+    int32_t reserved0;
     int32_t exchange_every;        /* strip driver: exchange m*g ghost rows every m-th launch; 0/1 = every launch */
     int32_t upload_strips;         /* hip::Grid upload in this many row strips overlapped with the first pass; 0 = rule */
     int32_t reserved[6];

@@ -133,7 +133,7 @@ class Options(C.Structure):
                    "max_generations", "allow_spilling_depths", "virtual_strips", "two_strips_permille",
                    "two_strips_permille_outer", "strip_skew_permille", "bands_beside_interior", "band_stream_priority",
                    "bands_apart", "bands_one_launch", "comm_stream_priority", "jacobi_fastpath", "conway_fastpath",
-                   "prepare_streams", "host_cache_mib", "pretend_neighbours", "exchange_every", "upload_strips")] + \
+                   "prepare_streams", "host_cache_mib", "reserved0", "exchange_every", "upload_strips")] + \
                [("reserved", C.c_int32 * 6)]
 
 
@@ -418,11 +418,16 @@ class Strip:
     (n_planes, send_up, send_down, recv_up, recv_down, row_bytes, n_rows, stream) -> None with the lists of device
     pointers of ststhip_comm_exchange_rows, for hosts whose ranks RCCL cannot join (tests)."""
 
-    def __init__(self, app, tf_params, halo_bytes, total_rows, width, rank, n_ranks, comm=None, exchange=None):
+    def __init__(self, app, tf_params, halo_bytes, total_rows, width, rank, n_ranks, comm=None, exchange=None,
+                 exchange_fn_address=None):
+        """exchange_fn_address: instead of `exchange`, the address of a C function with the ststhip_exchange_fn
+        signature (timing studies that must not pay for a Python callback per exchange)."""
         _sync_options()
         self._callback = None
         cb = None
-        if exchange is not None:
+        if exchange_fn_address is not None:
+            cb = C.c_void_p(int(exchange_fn_address))
+        elif exchange is not None:
             def trampoline(_ctx, n_planes, su, sd, ru, rd, rb, n_rows, stream):
                 try:
                     exchange(n_planes, [su[i] for i in range(n_planes)], [sd[i] for i in range(n_planes)],

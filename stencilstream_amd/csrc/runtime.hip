@@ -79,11 +79,6 @@ static ststhip_options read_options() {
     o.conway_fastpath = env_int("STSTHIP_CONWAY_FASTPATH", 1);
     o.prepare_streams = env_int("STSTHIP_PREPARE_STREAMS", 0);
     o.host_cache_mib = env_int("STSTHIP_HOST_CACHE_MIB", 4096);
-#ifdef STSTHIP_EXPERIMENTS
-    // timing studies on one GPU: launch the bands a strip with neighbours on both sides launches, without the
-    // exchange -- the rows at the strip's ends are then WRONG, which is why the product build has no such switch
-    o.pretend_neighbours = env_int("STSTHIP_STRIP_PRETEND_NEIGHBOURS", 0);
-#endif
     o.exchange_every = env_int("STSTHIP_EXCHANGE_EVERY", 0);
     o.upload_strips = env_int("STSTHIP_UPLOAD_STRIPS", 0);
     return o;
@@ -1616,7 +1611,7 @@ struct Strip {
     void *planes[2][16] = {{nullptr}};
     int current = 0;
     hipStream_t compute = nullptr, comm_stream = nullptr;
-    std::vector<hipStream_t> side, band; // interiors of further sub-strips; boundary bands (highest priority)
+    std::vector<hipStream_t> band; // the boundary bands' stream (highest priority), created when first needed
     ststhip_domain dom;        // geometry of the buffers (in words for the packed Game of Life)
     std::uint64_t n_launches = 0, n_exchanges = 0;
 };
@@ -1663,14 +1658,24 @@ int finish_strip(Strip *st, const ststhip_domain *dom, ststhip_strip *strip) {
     }
     st->n_planes = d.n_planes;
     st->g_max = std::uint64_t(d.max_generations) * d.halo_depth_per_generation;
-    st->exchange_every = st->n_ranks > 1 ? std::min(std::max(opt().exchange_every, 1), 16) : 1;
-    st->ghost = st->g_max * std::uint64_t(st->exchange_every);
     std::uint64_t thinnest = st->total_rows;
     for (int r = 0; r < st->n_ranks; r++) {
         std::uint64_t a, b;
         strip_bounds(st->total_rows, st->n_ranks, r, a, b);
         thinnest = std::min(thinnest, b - a);
     }
+    // launches per ghost exchange (STSTHIP_EXCHANGE_EVERY, else by the strips' height): a thin strip's launch is as
+    // short as the band -> exchange chain in front of the next one, so it groups four launches per exchange, a thick
+    // one two (one MI355X, the compute side of a rank, profiles/r03_thin_strips.txt: 2048 rows 3910 / 4010 / 4090
+    // Gcell/s per GPU at 1 / 2 / 4 launches per exchange)
+    st->exchange_every = 1;
+    if (st->n_ranks > 1) {
+        int every = opt().exchange_every > 0 ? std::min(opt().exchange_every, 16) : (thinnest < 4096 ? 4 : 2);
+        while (every > 1 && thinnest < 4 * st->g_max * std::uint64_t(every))
+            every--;
+        st->exchange_every = every;
+    }
+    st->ghost = st->g_max * std::uint64_t(st->exchange_every);
     if (st->n_ranks > 1 && thinnest < 2 * st->ghost) {
         delete st;
         return fail(STSTHIP_ERR_INVALID, "strips are thinner than two ghost depths: use fewer ranks, a larger grid or a "
@@ -1791,10 +1796,6 @@ int ststhip_strip_destroy(ststhip_strip strip) {
         (void)hipStreamSynchronize(st->compute);
     if (st->comm_stream)
         (void)hipStreamSynchronize(st->comm_stream);
-    for (hipStream_t lane : st->side) {
-        (void)hipStreamSynchronize(lane);
-        (void)hipStreamDestroy(lane);
-    }
     for (hipStream_t lane : st->band) {
         (void)hipStreamSynchronize(lane);
         (void)hipStreamDestroy(lane);
@@ -1871,19 +1872,29 @@ int ststhip_strip_warm_up(ststhip_strip strip) {
     return STSTHIP_OK;
 }
 
-// ststhip_strip_advance with STSTHIP_EXCHANGE_EVERY = m > 1: the launches of a call go in groups of m with ONE ghost
-// exchange per group.  Before a group the neighbours exchange G = sum of the group's halo depths g_j ghost rows; launch
-// j of the group then produces its owned rows widened by E_j = g_(j+1) + ... + g_(m-1) rows on every side that has a
-// neighbour (both neighbours compute those rows: g*m*(m-1) redundant rows per group, 2 % of a 2048-row strip at m = 4,
-// T = 12), so the next launch finds its halo without a message.  Only the LAST launch of a group is split: its top
-// and bottom G' rows (G' = ghost depth of the next group) run as one band launch on the highest-priority stream, the
-// exchange for the next group follows them on the comm stream, and the interior runs beside both.  Per group: one
-// band launch and one exchange instead of m of each -- for thin strips, where the band -> exchange -> band chain of
-// every launch is as long as the interior.  One sub-strip per rank.
-namespace {
-int strip_advance_grouped(Strip *st, std::uint64_t iteration_offset, std::uint64_t n_generations, int blocking,
-                          std::vector<std::uint32_t> const &depths) {
+// One call = n_generations generations of the whole distributed grid (every rank calls it with the same arguments).
+//
+// The launches of a call go in GROUPS of m = exchange_every launches with ONE ghost exchange per group.  Before a
+// group the neighbours exchange G = the sum of the group's halo depths g_j rows; launch j of the group then produces
+// the owned rows widened by E_j = g_(j+1) + ... + g_(m-1) on every side that has a neighbour (both ranks compute those
+// rows: g*m*(m-1) redundant rows per group and boundary, 2 % of a 2048-row strip at m = 4, T = 12), so the next launch
+// finds its halo without a message.  Only the LAST launch of a group is split: the G' rows next to each neighbour
+// (G' = ghost depth of the next group) run as ONE band launch with a row hole on a highest-priority stream, the
+// exchange for the next group follows it on the comm stream, and the interior runs beside both.  Per group: one band
+// launch and one exchange, however many launches it has -- for thin strips, where the band -> exchange -> band chain
+// of every launch was as long as the interior (m = 1 is the scheme of round 2: bands and exchange at every launch).
+// The owned rows are NOT cut into sub-strips any more: with the staged sweep two sub-strips on two streams measured
+// 3-20 % slower than one at 2048 ... 8192 rows, with band launches at their common boundary (round 2's scheme) and
+// with redundant halos instead (profiles/r03_thin_strips.txt).
+int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64_t n_generations, int blocking) {
+    Strip *st = static_cast<Strip *>(strip);
+    if (!st)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
     const ststhip_sweep_desc &d = st->resolved.desc;
+    const std::vector<std::uint32_t> depths = plan_depths(n_generations, d.max_generations);
+    if (depths.empty())
+        return STSTHIP_OK;
+    st->resolved.set_run(iteration_offset, n_generations);
     const std::uint64_t hpg = d.halo_depth_per_generation;
     const std::uint64_t a = st->row_begin, b = st->row_end;
     const std::size_t m = std::size_t(st->exchange_every);
@@ -1905,25 +1916,31 @@ int strip_advance_grouped(Strip *st, std::uint64_t iteration_offset, std::uint64
         if (ev)
             ordered(hipStreamWaitEvent(who, ev, 0), "hipStreamWaitEvent");
     };
-    if (st->band.empty()) {
-        hipStream_t lane;
-        if (create_band_stream(&lane) != hipSuccess)
-            return hip_fail(hipErrorUnknown, "hipStreamCreateWithPriority");
-        st->band.push_back(lane);
+
+    const bool has_up = st->rank > 0, has_down = st->rank + 1 < st->n_ranks;
+    hipStream_t lane = st->compute, band = nullptr;
+    if (has_up || has_down) {
+        // (created when first needed: streams are dealt onto a few hardware queues in creation order, idle ones included)
+        if (st->band.empty()) {
+            hipStream_t high;
+            if (create_band_stream(&high) != hipSuccess)
+                return hip_fail(hipErrorUnknown, "hipStreamCreateWithPriority");
+            st->band.push_back(high);
+        }
+        band = st->band[0];
     }
-    hipStream_t band = st->band[0];
-    const bool pretend = opt().pretend_neighbours != 0;
-    const bool has_up = st->rank > 0 || pretend, has_down = st->rank + 1 < st->n_ranks || pretend;
     g_launch_concurrency = 1;
+
+    // one device table of time-dependent values for the whole call, as in ststhip_run_passes
     void *tdv_table = nullptr;
     if (d.tdv_size > 0 && d.fill_tdv) {
         const std::size_t bytes = std::size_t(d.tdv_size) * n_generations;
-        rc = ststhip_malloc_async(&tdv_table, bytes, st->compute);
+        rc = ststhip_malloc_async(&tdv_table, bytes, lane);
         if (rc == STSTHIP_OK) {
             std::vector<unsigned char> values(bytes);
             d.fill_tdv(st->resolved.ctx, iteration_offset, n_generations, values.data());
-            ordered(hipMemcpyAsync(tdv_table, values.data(), bytes, hipMemcpyHostToDevice, st->compute), "hipMemcpyAsync");
-            ordered(hipStreamSynchronize(st->compute), "hipStreamSynchronize"); // `values` is pageable and goes out of scope
+            ordered(hipMemcpyAsync(tdv_table, values.data(), bytes, hipMemcpyHostToDevice, lane), "hipMemcpyAsync");
+            ordered(hipStreamSynchronize(lane), "hipStreamSynchronize"); // `values` is pageable and goes out of scope
             g_tdv_table = tdv_table;
             g_tdv_first = iteration_offset;
             g_tdv_count = n_generations;
@@ -1936,10 +1953,11 @@ int strip_advance_grouped(Strip *st, std::uint64_t iteration_offset, std::uint64
             sum += depths[i] * hpg;
         return sum;
     };
-    hipEvent_t begin = record(st->compute);
+    hipEvent_t begin = record(lane); // everything queued so far: a previous advance, uploads, the table
     wait(st->comm_stream, begin);
-    wait(band, begin);
-    hipEvent_t ghosts_ready = nullptr, bands_done = nullptr;
+    if (band)
+        wait(band, begin);
+    hipEvent_t ghosts_ready = nullptr;
     if (st->n_ranks > 1 && rc == STSTHIP_OK) {
         rc = strip_exchange(*st, st->current, group_depth(0));
         ghosts_ready = record(st->comm_stream);
@@ -1947,9 +1965,7 @@ int strip_advance_grouped(Strip *st, std::uint64_t iteration_offset, std::uint64
     std::uint64_t iteration = iteration_offset;
     for (std::size_t first = 0; first < depths.size() && rc == STSTHIP_OK; first += m) {
         const std::size_t last = std::min(first + m, depths.size()) - 1;
-        // the group's first launch reads the ghost rows of this group and everything the previous group left
-        wait(st->compute, ghosts_ready);
-        wait(st->compute, bands_done);
+        wait(lane, ghosts_ready); // the group's first launch reads the ghost rows of this group
         std::uint64_t widen = group_depth(first); // E_(j-1): how far beyond the owned rows the launch's input is valid
         for (std::size_t i = first; i <= last && rc == STSTHIP_OK; i++) {
             const std::uint32_t depth = depths[i];
@@ -1969,10 +1985,9 @@ int strip_advance_grouped(Strip *st, std::uint64_t iteration_offset, std::uint64
                 const std::uint64_t next = group_depth(last + 1);
                 const std::uint64_t top_end = has_up ? a + next : a;
                 const std::uint64_t bot_begin = has_down ? b - next : b;
-                // the bands read what the previous launch (compute stream) or, in a group of one, the exchange left
-                wait(band, record(st->compute));
-                wait(band, ghosts_ready);
-                if (a < top_end && bot_begin < b && top_end < bot_begin) {
+                wait(band, record(lane)); // the bands read what the previous launch left (and what `lane` waited for)
+                if (has_up && has_down && top_end < bot_begin) {
+                    // both bands as one launch with a hole where the interior is: one band latency in front of the exchange
                     g_row_hole_begin = top_end;
                     g_row_hole_end = bot_begin;
                     sweep(a, b, band);
@@ -1981,15 +1996,16 @@ int strip_advance_grouped(Strip *st, std::uint64_t iteration_offset, std::uint64
                     sweep(a, top_end, band);
                     sweep(bot_begin, b, band);
                 }
-                bands_done = record(band);
+                hipEvent_t banded = record(band);
                 if (st->n_ranks > 1 && rc == STSTHIP_OK) {
-                    wait(st->comm_stream, bands_done);
+                    wait(st->comm_stream, banded);
                     rc = strip_exchange(*st, st->current ^ 1, next);
                     ghosts_ready = record(st->comm_stream);
                 }
-                sweep(top_end, bot_begin, st->compute);
+                sweep(top_end, bot_begin, lane);
+                wait(lane, banded); // the next launch reads the bands' rows
             } else {
-                sweep(lo, hi, st->compute);
+                sweep(lo, hi, lane);
             }
             st->current ^= 1;
             iteration += depth;
@@ -1997,229 +2013,18 @@ int strip_advance_grouped(Strip *st, std::uint64_t iteration_offset, std::uint64
     }
     g_tdv_table = nullptr;
     g_tdv_count = 0;
-    wait(st->compute, record(band));
-    wait(st->compute, record(st->comm_stream));
-    if (rc == STSTHIP_OK && blocking) {
-        hipError_t err = hipStreamSynchronize(st->compute);
-        if (err != hipSuccess)
-            rc = hip_fail(err, "hipStreamSynchronize");
-    }
-    if (tdv_table)
-        ststhip_free_async(tdv_table, st->compute);
-    return rc;
-}
-} // namespace
-
-// One call = n_generations generations of the whole distributed grid.  Per pass p (buffer sets ping-pong, g = halo
-// rows of the pass):
-//     sub-strip v (own stream): wait(bands of v-1, v+1 of pass p-1; outermost: the ghost rows of pass p)
-//                               -> top band, bottom band -> [bands event] -> interior
-//     comm stream             : wait(bands events of the outermost sub-strips) -> exchange for pass p+1
-// so the exchange for pass p+1 runs beside the interiors of pass p.  A band reads rows up to 2g into its own
-// sub-strip and g into the neighbour, all of the previous pass; bands and interior of one pass write disjoint rows.
-int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64_t n_generations, int blocking) {
-    Strip *st = static_cast<Strip *>(strip);
-    if (!st)
-        return fail(STSTHIP_ERR_INVALID, "null argument");
-    const ststhip_sweep_desc &d = st->resolved.desc;
-    const std::vector<std::uint32_t> depths = plan_depths(n_generations, d.max_generations);
-    if (depths.empty())
-        return STSTHIP_OK;
-    st->resolved.set_run(iteration_offset, n_generations);
-    if (st->exchange_every > 1)
-        return strip_advance_grouped(st, iteration_offset, n_generations, blocking, depths);
-    const std::uint64_t hpg = d.halo_depth_per_generation;
-    const std::uint64_t a = st->row_begin, b = st->row_end;
-    int rc = STSTHIP_OK;
-    EventPool events;
-    auto ordered = [&](hipError_t err, const char *what) {
-        if (err != hipSuccess && rc == STSTHIP_OK)
-            rc = hip_fail(err, what);
-    };
-    auto record = [&](hipStream_t on) {
-        hipEvent_t ev = events.take();
-        if (!ev)
-            ordered(hipErrorUnknown, "hipEventCreateWithFlags");
-        else
-            ordered(hipEventRecord(ev, on), "hipEventRecord");
-        return ev;
-    };
-    auto wait = [&](hipStream_t who, hipEvent_t ev) {
-        if (ev)
-            ordered(hipStreamWaitEvent(who, ev, 0), "hipStreamWaitEvent");
-    };
-
-    // sub-strips of the owned rows, the rule of the single-GPU pass driver
-    const bool pretend = opt().pretend_neighbours != 0; // EXPERIMENTS builds only, 0 in the product library
-    const bool neighbours = st->n_ranks > 1 || pretend;
-    int n_sub = suggest_row_strips(b - a, st->dom.global_width, d.strip_width, st->g_max, depths.size(), neighbours);
-    n_sub = std::min(n_sub, 2);
-    while (n_sub > 1 && (b - a) < std::uint64_t(n_sub) * 2 * std::max<std::uint64_t>(st->g_max, 1))
-        n_sub--;
-    std::vector<std::uint64_t> bound(n_sub + 1);
-    for (int v = 0; v <= n_sub; v++)
-        bound[v] = a + (b - a) * std::uint64_t(v) / std::uint64_t(n_sub);
-    if (n_sub == 2 && !opt().bands_beside_interior)
-        bound[1] = a + (b - a) * 2 / 5; // bands in front of the interiors: unequal strips drift out of phase
-    while (int(st->side.size()) < n_sub - 1) {
-        hipStream_t lane;
-        if (hipStreamCreateWithFlags(&lane, hipStreamNonBlocking) != hipSuccess)
-            return hip_fail(hipErrorUnknown, "hipStreamCreateWithFlags");
-        st->side.push_back(lane);
-    }
-    std::vector<hipStream_t> lanes(n_sub, st->compute);
-    for (int v = 1; v < n_sub; v++)
-        lanes[v] = st->side[v - 1];
-    // boundary bands on a highest-priority stream of their own, beside the interior of the same sub-strip and pass (the
-    // dependency rule of ststhip_run_passes; bands at the strip's ends additionally wait for the ghost rows).  A band
-    // is a dependent chain of 3g row steps per wave: 55-120 us beside a busy interior, and the two bands of a
-    // sub-strip follow each other in one stream.  STSTHIP_BANDS_APART=1 gives the top and the bottom band a stream
-    // each: measured 5-25 % slower (more streams than hardware queues; profiles/r02_thin_strips.txt), so it is off.
-    const bool bands_beside = opt().bands_beside_interior != 0;
-    const bool bands_apart = bands_beside && opt().bands_apart != 0;
-    const bool bands_one_launch = opt().bands_one_launch != 0;
-    // (only as many as are used: streams are dealt onto a few hardware queues in creation order, idle ones included)
-    const int n_band_streams = bands_apart ? 2 * n_sub : n_sub;
-    while (bands_beside && int(st->band.size()) < n_band_streams) {
-        hipStream_t lane;
-        if (create_band_stream(&lane) != hipSuccess)
-            return hip_fail(hipErrorUnknown, "hipStreamCreateWithPriority");
-        st->band.push_back(lane);
-    }
-    const bool has_up = st->rank > 0 || pretend, has_down = st->rank + 1 < st->n_ranks || pretend;
-    g_launch_concurrency = n_sub;
-
-    // one device table of time-dependent values for the whole call, as in ststhip_run_passes (the launches then take
-    // their values from it instead of evaluating them on the host one launch at a time)
-    void *tdv_table = nullptr;
-    if (d.tdv_size > 0 && d.fill_tdv && rc == STSTHIP_OK) {
-        const std::size_t bytes = std::size_t(d.tdv_size) * n_generations;
-        rc = ststhip_malloc_async(&tdv_table, bytes, st->compute);
-        if (rc == STSTHIP_OK) {
-            std::vector<unsigned char> values(bytes);
-            d.fill_tdv(st->resolved.ctx, iteration_offset, n_generations, values.data());
-            ordered(hipMemcpyAsync(tdv_table, values.data(), bytes, hipMemcpyHostToDevice, st->compute), "hipMemcpyAsync");
-            ordered(hipStreamSynchronize(st->compute), "hipStreamSynchronize"); // `values` is pageable and goes out of scope
-            g_tdv_table = tdv_table;
-            g_tdv_first = iteration_offset;
-            g_tdv_count = n_generations;
-            g_tdv_size = d.tdv_size;
-        }
-    }
-    hipEvent_t begin = record(st->compute); // everything queued so far: a previous advance, uploads, the table
-    wait(st->comm_stream, begin);
-    for (int v = 1; v < n_sub; v++)
-        wait(lanes[v], begin);
-    if (bands_beside)
-        for (int v = 0; v < n_band_streams; v++)
-            wait(st->band[v], begin);
-    hipEvent_t ghosts_ready = nullptr;
-    if (st->n_ranks > 1 && rc == STSTHIP_OK) {
-        rc = strip_exchange(*st, st->current, depths[0] * hpg);
-        ghosts_ready = record(st->comm_stream);
-    }
-    struct BandEvents {
-        hipEvent_t top = nullptr, bottom = nullptr;
-    };
-    auto wait_bands = [&](hipStream_t who, BandEvents const &ev) {
-        wait(who, ev.top);
-        if (ev.bottom != ev.top)
-            wait(who, ev.bottom);
-    };
-    std::vector<BandEvents> bands_done(n_sub);
-    std::vector<hipEvent_t> interior_done(n_sub, nullptr);
-    std::uint64_t iteration = iteration_offset;
-    for (std::size_t i = 0; i < depths.size() && rc == STSTHIP_OK; i++) {
-        const std::uint32_t depth = depths[i];
-        const std::uint64_t g = depth * hpg;
-        const void *const *src = const_cast<const void *const *>(st->planes[st->current]);
-        void *const *dst = st->planes[st->current ^ 1];
-        std::vector<BandEvents> bands_now(n_sub);
-        std::vector<hipEvent_t> interior_now(n_sub, nullptr);
-        for (int v = 0; v < n_sub && rc == STSTHIP_OK; v++) {
-            const std::uint64_t va = bound[v], vb = bound[v + 1];
-            hipStream_t lane = lanes[v];
-            hipStream_t top_on = bands_beside ? st->band[bands_apart ? 2 * v : v] : lane;
-            hipStream_t bottom_on = bands_apart ? st->band[2 * v + 1] : top_on;
-            const bool up = v > 0 || has_up;            // somebody above needs (and feeds) my top rows
-            const bool down = v + 1 < n_sub || has_down;
-            // a band reads rows of the previous pass up to 2g into its own sub-strip (its interior, and in a thin
-            // sub-strip the other band) and g into the neighbour, and overwrites rows those launches read
-            for (hipStream_t on : {top_on, bottom_on}) {
-                if (v > 0)
-                    wait_bands(on, bands_done[v - 1]);
-                if (v + 1 < n_sub)
-                    wait_bands(on, bands_done[v + 1]);
-                if ((v == 0 && has_up) || (v == n_sub - 1 && has_down))
-                    wait(on, ghosts_ready);
-                if (bands_beside)
-                    wait(on, interior_done[v]);
-                if (bands_apart)
-                    wait_bands(on, bands_done[v]);
-                if (bottom_on == top_on)
-                    break;
-            }
-            const std::uint64_t top_end = up ? std::min(va + g, vb) : va;
-            const std::uint64_t bot_begin = down ? std::max(vb - std::min(g, vb - va), top_end) : vb;
-            auto sweep = [&](std::uint64_t r0, std::uint64_t r1, hipStream_t on) {
-                if (r0 < r1 && rc == STSTHIP_OK) {
-                    rc = st->resolved.trampoline(st->resolved.ctx, &st->dom, src, dst, r0, r1, iteration, depth, on);
-                    st->n_launches++;
-                }
-            };
-            if (bands_one_launch && n_sub == 1 && top_on == bottom_on && va < top_end && top_end < bot_begin && bot_begin < vb) {
-                // both bands as one launch with a hole where the interior is: one band latency per pass, not two, in
-                // front of the exchange for the next pass (a strip thin enough for one sub-strip is the case where
-                // band + exchange can take longer than the interior; with two sub-strips it measured 3 % slower)
-                g_row_hole_begin = top_end;
-                g_row_hole_end = bot_begin;
-                sweep(va, vb, top_on);
-                g_row_hole_begin = g_row_hole_end = 0;
-            } else {
-                sweep(va, top_end, top_on);
-                sweep(bot_begin, vb, bottom_on);
-            }
-            bands_now[v].top = record(top_on);
-            bands_now[v].bottom = bottom_on == top_on ? bands_now[v].top : record(bottom_on);
-            if (bands_beside) {
-                // the interior reads the rows of this sub-strip's previous bands and, when this pass is shallower
-                // than the previous one, overwrites rows next to them that the neighbours' previous bands read
-                for (int w = std::max(v - 1, 0); w <= std::min(v + 1, n_sub - 1); w++)
-                    wait_bands(lane, bands_done[w]);
-            }
-            sweep(top_end, bot_begin, lane);
-            if (bands_beside)
-                interior_now[v] = record(lane);
-        }
-        if (i + 1 < depths.size() && st->n_ranks > 1 && rc == STSTHIP_OK) {
-            wait_bands(st->comm_stream, bands_now[0]);
-            wait_bands(st->comm_stream, bands_now[n_sub - 1]);
-            rc = strip_exchange(*st, st->current ^ 1, depths[i + 1] * hpg);
-            ghosts_ready = record(st->comm_stream);
-        }
-        bands_done.swap(bands_now);
-        interior_done.swap(interior_now);
-        st->current ^= 1;
-        iteration += depth;
-    }
-    g_launch_concurrency = 1;
-    g_tdv_table = nullptr;
-    g_tdv_count = 0;
     // the compute stream is the one callers synchronise with
-    for (int v = 1; v < n_sub; v++)
-        wait(st->compute, record(lanes[v]));
-    if (bands_beside)
-        for (int v = 0; v < n_band_streams; v++)
-            wait(st->compute, record(st->band[v]));
-    wait(st->compute, record(st->comm_stream));
+    if (band)
+        wait(lane, record(band));
+    wait(lane, record(st->comm_stream));
     if (rc == STSTHIP_OK && blocking) {
-        hipError_t err = hipStreamSynchronize(st->compute);
+        hipError_t err = hipStreamSynchronize(lane);
         if (err != hipSuccess)
             rc = hip_fail(err, "hipStreamSynchronize");
     }
     if (tdv_table)
-        ststhip_free_async(tdv_table, st->compute); // every stream has been joined into the compute stream above
-    return rc; // the events go back to the pool (EventPool): a recorded event may be re-recorded once it is no longer waited for
+        ststhip_free_async(tdv_table, lane); // every stream has been joined into the compute stream above
+    return rc; // the events go back to the pool (EventPool)
 }
 
 } // extern "C"

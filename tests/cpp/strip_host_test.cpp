@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr std::size_t H = 1500, W = 1100, max_rows = 16;
+constexpr std::size_t H = 1500, W = 1100, max_rows = 128; // ghost rows of one exchange: up to four launches of 16 rows
 constexpr std::uint64_t generations_a = 29, generations_b = 11;
 
 #define CHECK(call)                                                                                 \

@@ -25,7 +25,7 @@
 using namespace stencil;
 
 namespace {
-constexpr std::size_t H = 700, W = 530, max_rows = 16, max_planes = 2;
+constexpr std::size_t H = 700, W = 530, max_rows = 128, max_planes = 2; // ghost rows of one exchange: up to four launches
 
 // a time-dependent value and two sub-iterations, exact in fp32 wherever it is evaluated
 struct Ramp {

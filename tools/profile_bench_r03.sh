@@ -4,8 +4,8 @@
 # of the same program in separate --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ instruction counts), as
 # MI355X_MICROARCH.md prescribes.  tools/summarize_bench_profile.py condenses the outputs into the files that are
 # committed under profiles/.
-# usage: tools/profile_bench_r02.sh <tag> [extra bench args...]
-TAG="${1:-r02_bench}"; shift
+# usage: tools/profile_bench_r03.sh <tag> [extra bench args...]
+TAG="${1:-r03_bench}"; shift
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (tools/profile_bench_r02.sh) into small files:
+"""Condense gpurun_out/prof_<tag>/ (tools/profile_bench_r03.sh) into small files:
 
   <tag>_kernel_stats.csv   rocprofv3 --stats table of `python3 bench.py --gpus 1 --steps 20 --warmup 5`
   <tag>_summary.json       per sweep kernel and launch shape: calls, average duration; for the timed steps the
@@ -164,10 +164,53 @@ def main():
                 entry[out] = per_counter[name]["mean"]
         counters["kernels"][key] = entry
     counters["raw"] = per_counter
+    # ---- the same counters summed over the launches of ONE TIMED STEP (interiors and bands of the row strips):
+    # every pass ran `--warmup 1 --steps 2`; a step is `launches_per_step` consecutive sweep launches in dispatch
+    # order (bench.py reports the number), the roofline leg's full-grid launches come after the three steps
+    counters["timed_step"] = {}
+    line = None
+    for log in ("sq.log", "fetch.log", "write.log"):
+        line = line or bench_line(os.path.join(src, log))
+    n_per_step = (line or {}).get("launches_per_step")
+    if key and n_per_step:
+        sums, shapes_seen, durations = {}, collections.Counter(), []
+        for kind in ("fetch", "write", "sq"):
+            f = newest(os.path.join(src, kind, "*", "*counter_collection.csv"))
+            if not f:
+                continue
+            rows = [r for r in csv.DictReader(open(f)) if "sweep_kernel" in r["Kernel_Name"]]
+            by_counter = collections.defaultdict(list)
+            for r in rows:
+                by_counter[r["Counter_Name"]].append(r)
+            for counter, rs in by_counter.items():
+                rs.sort(key=lambda r: int(r["Dispatch_Id"]))
+                steps = [rs[i * n_per_step:(i + 1) * n_per_step] for i in (1, 2)]  # the two timed steps
+                if any(len(st) != n_per_step for st in steps):
+                    continue
+                sums[counter] = sum(float(r["Counter_Value"]) for st in steps for r in st) / len(steps)
+                if counter in ("FETCH_SIZE", "SQ_INSTS_VALU"):
+                    durations.append(sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for st in steps for r in st) / len(steps))
+                if counter == "FETCH_SIZE":
+                    for r in steps[0]:
+                        shapes_seen[grid_size(r)] += 1
+        if "FETCH_SIZE" in sums and "WRITE_SIZE" in sums:
+            counters["timed_step"][key] = {
+                "launches_per_step": n_per_step,
+                "launch_shapes": {str(k): v for k, v in sorted(shapes_seen.items())},
+                "hbm_bytes_per_step": 2 * sums["FETCH_SIZE"] * 1024 + sums["WRITE_SIZE"] * 1024,
+                "hbm_read_bytes_per_step": 2 * sums["FETCH_SIZE"] * 1024,
+                "hbm_write_bytes_per_step": sums["WRITE_SIZE"] * 1024,
+                "valu_wave_instructions_per_step": sums.get("SQ_INSTS_VALU"),
+                "waves_per_step": sums.get("SQ_WAVES"),
+                "sum_kernel_ms_per_step": (sum(durations) / len(durations) / 1e6) if durations else None,
+                "source": "the same PMC passes: counter values summed over the sweep launches of one timed step "
+                          "(launch_shapes: grid size -> launches per step); FETCH_SIZE doubled as above",
+            }
     json.dump(summary, open(os.path.join(src, f"{tag}_summary.json"), "w"), indent=1)
     json.dump(counters, open(os.path.join(src, f"{tag}_counters.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k != "bench_line"}, indent=1)[:2500])
     print(json.dumps(counters["kernels"], indent=1)[:2000])
+    print(json.dumps(counters["timed_step"], indent=1)[:2000])
 
 
 if __name__ == "__main__":
