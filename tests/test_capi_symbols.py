@@ -31,7 +31,30 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 
 def test_abi_version(built_lib):
-    assert built_lib.ststhip_abi_version() == 3
+    assert built_lib.ststhip_abi_version() == 4
+
+
+def test_options_come_from_the_environment_once(built_lib, monkeypatch):
+    """ststhip_options: the tuning knobs are read once, not per launch; ststhip_reload_options re-reads them; the
+    Python struct mirrors the C one (the last field of the C struct is where ctypes expects it)."""
+    from stencilstream_amd import capi
+
+    capi.reload_options()
+    o = capi.options()
+    assert (o.narrow_form_kcells, o.n_taper, o.skip_constant_stores, o.host_cache_mib) == (20000, -1, 1, 4096)
+    monkeypatch.setenv("STSTHIP_CHUNK_ROWS", "77")
+    monkeypatch.setenv("STSTHIP_TAPER", "150:2,50:4")
+    monkeypatch.setenv("STSTHIP_UPLOAD_STRIPS", "3")
+    assert capi.options().chunk_rows == 0  # not re-read behind the host's back
+    capi.reload_options()
+    o = capi.options()
+    assert o.chunk_rows == 77 and o.n_taper == 2 and list(o.taper_permille)[:2] == [150, 50] and list(o.taper_split)[:2] == [2, 4]
+    assert o.upload_strips == 3
+    monkeypatch.delenv("STSTHIP_CHUNK_ROWS")
+    monkeypatch.delenv("STSTHIP_TAPER")
+    monkeypatch.delenv("STSTHIP_UPLOAD_STRIPS")
+    capi.reload_options()
+    assert capi.options().chunk_rows == 0
 
 
 def test_registry_describes_the_apps(built_lib):
@@ -42,7 +65,7 @@ def test_registry_describes_the_apps(built_lib):
                  "jacobi5constant", "jacobi4general", "jacobi5general", "jacobi9general", "hotspot",
                  "hotspot_aos", "hotspot_f64", "hotspot_f64_aos", "jacobi5uniform", "jacobi5uniform_first",
                  "jacobi5uniform_last", "jacobi5uniform_only", "jacobi5general_fma", "conway", "conway_packed", "selfcheck1", "selfcheck1_soa", "selfcheck2", "fdtd_coef",
-                 "fdtd_coef_aos"):
+                 "fdtd_coef_aos", "fdtd_coef_grouped", "jacobi5general_independent", "hotspot_independent"):
         assert name in apps
     j = capi.app_info("jacobi5general")
     assert (j.cell_size, j.n_planes, j.stencil_radius, j.n_subiterations, j.tdv_size) == (4, 1, 1, 1, 0)
