@@ -294,26 +294,51 @@ template <typename F, bool SOA> struct SweepTuning {
     }
 
     // Stages (Sweep.hpp head): four waves per column strip where the levels divide by four, else two, as long as
-    // the row rings between the stages stay within 40 KiB of LDS per workgroup (four workgroups per CU).  Measured on
+    // the row rings between the stages stay within 48 KiB of LDS per workgroup (three workgroups per CU).  Measured on
     // MI355X (profiles/r03_tune_staged.txt), full grids / 2048-row strips: Jacobi5General +3 % / +14 %, the packed
     // Game of Life +29 %, HotSpot +18 %, FDTD +13...23 %; launches of a few rows (boundary bands) run a third as long.
     static constexpr int ring_bytes(int w, int k, int p) {
         return (w - 1) * 2 * p * 64 * k * int((sizeof(typename F::Cell) + 3) / 4) * 4;
     }
+    static constexpr int lds_limit = 48 * 1024; // three workgroups per CU at least
+    struct Shape {
+        int t, p, w;
+    };
     static constexpr int pick_w(int t, int k, int p) {
         for (int w : {4, 2})
-            if ((t * NS) % w == 0 && ring_bytes(w, k, p) <= 40 * 1024)
+            if ((t * NS) % w == 0 && ring_bytes(w, k, p) <= lds_limit)
                 return w;
         return 1;
+    }
+    // Fat cells with sub-iterations (eight words and more per generation: FDTD, convection) are limited by the
+    // register window, not by anything else; a stage keeps the window of its own levels only, so with stages the
+    // launch can be deeper than one wave could hold: the deepest T <= 8 whose window PER STAGE stays within what the
+    // unstaged shape was admitted with (128 words, or one generation's window where even that is more), the rings
+    // within the LDS budget (batches of 2R rows).  FDTD: T = 6 -> 8 on four stages (the precompiled form's
+    // measured optimum, profiles/r03_tune_staged.txt); convection's 88-byte fp64 cell with three sub-iterations: T = 1 ->
+    // 2 on three stages, 134.6 -> 88.4 us per iteration at res = 1024 (T = 2 on two stages spills: 132.8; T = 1 on
+    // three: 148.3; profiles/r03_convection.txt).
+    static constexpr Shape pick_shape(int k) {
+        const int t0 = pick_t(k);
+        const int p0 = pick_p(t0, k);
+        if (R == 1 && W * NS >= 8) {
+            const int admitted = std::max(128, nominal_window(1, k));
+            for (int t : {8, 4, 2})
+                for (int w : {4, 3, 2})
+                    if (t > t0 && (t * NS) % w == 0 && nominal_window(t, k) / w <= admitted && geometry_ok(t, k) &&
+                        ring_bytes(w, k, 2 * R) <= lds_limit)
+                        return Shape{t, 2 * R, w}; // batches of 2R rows: the smallest rings
+        }
+        return Shape{t0, p0, pick_w(t0, k, p0)};
     }
 
   public:
     static constexpr int cells_per_lane = pick_k();
-    static constexpr int max_generations = pick_t(cells_per_lane);
-    static constexpr int prefetch_rows = pick_p(max_generations, cells_per_lane);
+    static constexpr int max_generations = pick_shape(cells_per_lane).t;
+    static constexpr int prefetch_rows = pick_shape(cells_per_lane).p;
     static constexpr bool interior_variant = (W * NS <= 16);
     static constexpr int min_waves_per_simd = 1;
-    static constexpr int stages = pick_w(max_generations, cells_per_lane, prefetch_rows);
+    static constexpr int stages = pick_shape(cells_per_lane).w;
 };
 
 namespace internal {

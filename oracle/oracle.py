@@ -224,3 +224,60 @@ def fdtd(params, cells, n_iterations, iteration_offset=0, n_threads=1):
     )
     assert rc == 0
     return out
+
+
+# ---- convection (examples/convection/convection.cpp:36-242): eleven fp64 fields
+CONVECTION_CELL = np.dtype([(n, "<f8") for n in ("T", "Pt", "Vx", "Vy", "tau_xx", "tau_yy", "sigma_xy", "dVxd_tau",
+                                                  "dVyd_tau", "ErrV", "ErrP")])
+
+
+class PseudoTransientParams(C.Structure):
+    _fields_ = [("nx", C.c_size_t), ("ny", C.c_size_t)] + [(n, C.c_double) for n in (
+        "roh0_g_alpha", "delta_eta_delta_T", "eta0", "deltaT", "dx", "dy", "delta_tau_iter", "beta", "rho", "dampX",
+        "dampY", "DcT")]
+
+
+class ThermalSolverParams(C.Structure):
+    _fields_ = [("nx", C.c_size_t), ("ny", C.c_size_t)] + [(n, C.c_double) for n in ("dx", "dy", "dt", "DcT")]
+
+
+def pseudo_transient(params, cells, n_iterations, iteration_offset=0, n_threads=1):
+    cells = np.ascontiguousarray(cells, dtype=CONVECTION_CELL)
+    out = np.empty_like(cells)
+    H, W = cells.shape
+    rc = lib().oracle_pseudo_transient(C.byref(params), _p(cells), _p(out), _sz(H), _sz(W), _sz(iteration_offset),
+                                       _sz(n_iterations), int(n_threads))
+    assert rc == 0
+    return out
+
+
+def thermal_solver(params, cells, n_iterations=1, iteration_offset=0, n_threads=1):
+    cells = np.ascontiguousarray(cells, dtype=CONVECTION_CELL)
+    out = np.empty_like(cells)
+    H, W = cells.shape
+    rc = lib().oracle_thermal_solver(C.byref(params), _p(cells), _p(out), _sz(H), _sz(W), _sz(iteration_offset),
+                                     _sz(n_iterations), int(n_threads))
+    assert rc == 0
+    return out
+
+
+def convection_dump_check(directory, n_iterations, n_threads=8):
+    """The files a build/examples/convection_dump_* binary wrote into `directory` against this oracle: returns the
+    number of cells that differ (all eleven fields compared as bits) per phase, and the number of cells compared."""
+    raw = open(f"{directory}/params.bin", "rb").read()
+    nx, ny = np.frombuffer(raw[:16], dtype="<u8")
+    v = np.frombuffer(raw[16:], dtype="<f8")
+    pt = PseudoTransientParams(int(nx), int(ny), *[float(x) for x in v[:12]])
+    ts = ThermalSolverParams(int(nx), int(ny), *[float(x) for x in v[14:18]])
+    shape = (int(nx) + 1, int(ny) + 1)
+    grid = np.fromfile(f"{directory}/init.bin", dtype=CONVECTION_CELL).reshape(shape)
+    differing = {}
+    for r in range(2):
+        grid = pseudo_transient(pt, grid, n_iterations, n_threads=n_threads)
+        got = np.fromfile(f"{directory}/round{r}_pt.bin", dtype=CONVECTION_CELL).reshape(shape)
+        differing[f"round{r}_pt"] = int((got.view("<u8").reshape(shape + (11,)) != grid.view("<u8").reshape(shape + (11,))).any(axis=-1).sum())
+        grid = thermal_solver(ts, grid, 1, n_threads=n_threads)
+        got = np.fromfile(f"{directory}/round{r}_ts.bin", dtype=CONVECTION_CELL).reshape(shape)
+        differing[f"round{r}_ts"] = int((got.view("<u8").reshape(shape + (11,)) != grid.view("<u8").reshape(shape + (11,))).any(axis=-1).sum())
+    moved = float(np.abs(grid["Vx"]).max())
+    return differing, shape[0] * shape[1], moved

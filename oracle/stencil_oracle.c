@@ -445,3 +445,114 @@ int oracle_fdtd(const oracle_fdtd_params *p, const oracle_fdtd_cell *in, oracle_
     oracle_function f = {sizeof(oracle_fdtd_cell), 1, 2, sizeof(float), fdtd_fn, fdtd_tdv, p};
     return oracle_run(&f, in, out, H, W, &halo, iteration_offset, n_iterations, n_threads);
 }
+
+/* ------------------------------------------------------------------ convection (examples/convection/convection.cpp) */
+#define CC(dr, dc) NB(st, oracle_convection_cell, dr, dc)
+
+static void pseudo_transient_fn(const void *vctx, const oracle_stencil *st, void *out) {
+    /* convection.cpp:95-176; the macros of :67-74 written out: D_XA(F) = [1][0].F - [0][0].F, D_YA(F) = [0][1].F -
+     * [0][0].F, D_XI(F) = [1][1].F - [0][1].F, D_YI(F) = [1][1].F - [1][0].F */
+    const oracle_pseudo_transient_params *k = (const oracle_pseudo_transient_params *)vctx;
+    oracle_convection_cell n = CC(0, 0);
+    const size_t x = st->row, y = st->col, nx = k->nx, ny = k->ny;
+    if (st->subiteration == 0) {
+        if (x < nx && y < ny + 1)
+            n.ErrV = CC(0, 0).Vy;
+        if (x < nx && y < ny)
+            n.ErrP = CC(0, 0).Pt;
+        if (x < nx && y < ny) {
+            double delta_V = (CC(1, 0).Vx - CC(0, 0).Vx) / k->dx + (CC(0, 1).Vy - CC(0, 0).Vy) / k->dy;
+            double eta = k->eta0 * (1.0 - k->delta_eta_delta_T * (CC(0, 0).T + k->deltaT / 2.0));
+            n.Pt = CC(0, 0).Pt - k->delta_tau_iter / k->beta * delta_V;
+            n.tau_xx = 2.0 * eta * ((CC(1, 0).Vx - CC(0, 0).Vx) / k->dx - (1.0 / 3.0) * delta_V);
+            n.tau_yy = 2.0 * eta * ((CC(0, 1).Vy - CC(0, 0).Vy) / k->dy - (1.0 / 3.0) * delta_V);
+            if (x < nx - 1 && y < ny - 1)
+                n.sigma_xy = eta * ((CC(1, 1).Vx - CC(1, 0).Vx) / k->dy + (CC(1, 1).Vy - CC(0, 1).Vy) / k->dx);
+        }
+    } else if (st->subiteration == 1) {
+        if (x >= 1 && y >= 1) {
+            if (x < (nx + 1) - 1 && y < ny - 1) {
+                double Rx = 1.0 / k->rho *
+                            ((CC(0, 0).tau_xx - CC(-1, 0).tau_xx) / k->dx +
+                             (CC(-1, 0).sigma_xy - CC(-1, -1).sigma_xy) / k->dy -
+                             (CC(0, 0).Pt - CC(-1, 0).Pt) / k->dx);
+                n.dVxd_tau = k->dampX * CC(0, 0).dVxd_tau + Rx * k->delta_tau_iter;
+                n.Vx = CC(0, 0).Vx + n.dVxd_tau * k->delta_tau_iter;
+            }
+            if (x < nx - 1 && y < (ny + 1) - 1) {
+                double Ry = 1.0 / k->rho *
+                            ((CC(0, 0).tau_yy - CC(0, -1).tau_yy) / k->dy +
+                             (CC(0, -1).sigma_xy - CC(-1, -1).sigma_xy) / k->dx -
+                             (CC(0, 0).Pt - CC(0, -1).Pt) / k->dy +
+                             k->roh0_g_alpha * ((CC(0, -1).T + CC(0, 0).T) * 0.5));
+                n.dVyd_tau = k->dampY * CC(0, 0).dVyd_tau + Ry * k->delta_tau_iter;
+                n.Vy = CC(0, 0).Vy + n.dVyd_tau * k->delta_tau_iter;
+            }
+        }
+    } else if (st->subiteration == 2) {
+        if (x < nx + 1 && y < ny) {
+            if (y == 0)
+                n.Vx = CC(0, 1).Vx;
+            if (y == ny - 1)
+                n.Vx = CC(0, -1).Vx;
+        }
+        if (x < nx && y < ny + 1) {
+            if (x == 0)
+                n.Vy = CC(1, 0).Vy;
+            if (x == nx - 1)
+                n.Vy = CC(-1, 0).Vy;
+        }
+        if (x < nx && y < ny + 1)
+            n.ErrV = CC(0, 0).ErrV - n.Vy;
+        if (x < nx && y < ny)
+            n.ErrP = CC(0, 0).ErrP - CC(0, 0).Pt;
+    }
+    *(oracle_convection_cell *)out = n;
+}
+
+int oracle_pseudo_transient(const oracle_pseudo_transient_params *p, const oracle_convection_cell *in,
+                            oracle_convection_cell *out, size_t H, size_t W, size_t iteration_offset,
+                            size_t n_iterations, int n_threads) {
+    const oracle_convection_cell halo = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; /* convection.cpp:42-56 */
+    oracle_function f = {sizeof(oracle_convection_cell), 1, 3, 0, pseudo_transient_fn, NULL, p};
+    return oracle_run(&f, in, out, H, W, &halo, iteration_offset, n_iterations, n_threads);
+}
+
+static void thermal_solver_fn(const void *vctx, const oracle_stencil *st, void *out) {
+    /* convection.cpp:190-240 */
+    const oracle_thermal_solver_params *k = (const oracle_thermal_solver_params *)vctx;
+    oracle_convection_cell n = CC(0, 0);
+    const size_t x = st->row, y = st->col, nx = k->nx, ny = k->ny;
+    if (st->subiteration == 0) {
+        if (x > 0 && y > 0 && x < nx - 1 && y < ny - 1) {
+            double qTx_top_left = -k->DcT * (CC(0, 0).T - CC(-1, 0).T) / k->dx;
+            double qTx_top = -k->DcT * (CC(1, 0).T - CC(0, 0).T) / k->dx;
+            double qTy_top_left = -k->DcT * (CC(0, 0).T - CC(0, -1).T) / k->dy;
+            double qTy_left = -k->DcT * (CC(0, 1).T - CC(0, 0).T) / k->dy;
+            double dT_dt = -((qTx_top - qTx_top_left) / k->dx + (qTy_left - qTy_top_left) / k->dy);
+            if (CC(0, 0).Vx > 0)
+                dT_dt -= CC(0, 0).Vx * (CC(0, 0).T - CC(-1, 0).T) / k->dx;
+            if (CC(1, 0).Vx < 0)
+                dT_dt -= CC(1, 0).Vx * (CC(1, 0).T - CC(0, 0).T) / k->dx;
+            if (CC(0, 0).Vy > 0)
+                dT_dt -= CC(0, 0).Vy * (CC(0, 0).T - CC(0, -1).T) / k->dy;
+            if (CC(0, 1).Vy < 0)
+                dT_dt -= CC(0, 1).Vy * (CC(0, 1).T - CC(0, 0).T) / k->dy;
+            n.T = CC(0, 0).T + dT_dt * k->dt;
+        }
+    } else if (st->subiteration == 1) {
+        if (x == nx - 1 && y < ny)
+            n.T = CC(-1, 0).T;
+        if (x == 0 && y < ny)
+            n.T = CC(1, 0).T;
+    }
+    *(oracle_convection_cell *)out = n;
+}
+
+int oracle_thermal_solver(const oracle_thermal_solver_params *p, const oracle_convection_cell *in,
+                          oracle_convection_cell *out, size_t H, size_t W, size_t iteration_offset,
+                          size_t n_iterations, int n_threads) {
+    const oracle_convection_cell halo = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    oracle_function f = {sizeof(oracle_convection_cell), 1, 2, 0, thermal_solver_fn, NULL, p};
+    return oracle_run(&f, in, out, H, W, &halo, iteration_offset, n_iterations, n_threads);
+}

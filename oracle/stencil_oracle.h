@@ -149,6 +149,29 @@ float oracle_fdtd_tdv(const oracle_fdtd_params *p, size_t iteration);
 int oracle_fdtd(const oracle_fdtd_params *p, const oracle_fdtd_cell *in, oracle_fdtd_cell *out,
                 size_t H, size_t W, size_t iteration_offset, size_t n_iterations, int n_threads);
 
+/* ---- Convection: examples/convection/convection.cpp:36-242 (fp64, 11-field cell) ----
+ * PseudoTransientKernel (three sub-iterations, :76-177) and ThermalSolverKernel (two, :179-242), restated with the
+ * reference's expressions in the reference's order.  dimension 0 is "x" (rows), dimension 1 "y" (columns).  The
+ * reference's tests hold no vector for them ("parity unpinned"); tests/test_oracle_golden.py checks this restatement
+ * against the reference's own functor source on this repository's stencil::cpu (examples/convection_oracle_test.cpp). */
+typedef struct {
+    double T, Pt, Vx, Vy, tau_xx, tau_yy, sigma_xy, dVxd_tau, dVyd_tau, ErrV, ErrP;
+} oracle_convection_cell;
+typedef struct {
+    size_t nx, ny;
+    double roh0_g_alpha, delta_eta_delta_T, eta0, deltaT, dx, dy, delta_tau_iter, beta, rho, dampX, dampY, DcT;
+} oracle_pseudo_transient_params;
+typedef struct {
+    size_t nx, ny;
+    double dx, dy, dt, DcT;
+} oracle_thermal_solver_params;
+int oracle_pseudo_transient(const oracle_pseudo_transient_params *p, const oracle_convection_cell *in,
+                            oracle_convection_cell *out, size_t H, size_t W, size_t iteration_offset,
+                            size_t n_iterations, int n_threads);
+int oracle_thermal_solver(const oracle_thermal_solver_params *p, const oracle_convection_cell *in,
+                          oracle_convection_cell *out, size_t H, size_t W, size_t iteration_offset,
+                          size_t n_iterations, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,7 +77,7 @@ static ststhip_options read_options() {
     o.comm_stream_priority = env_int("STSTHIP_COMM_STREAM_PRIORITY", 0);
     o.jacobi_fastpath = env_int("STSTHIP_JACOBI_FASTPATH", 1);
     o.conway_fastpath = env_int("STSTHIP_CONWAY_FASTPATH", 1);
-    o.prepare_streams = env_int("STSTHIP_PREPARE_STREAMS", 0);
+    o.prepare_streams = env_int("STSTHIP_PREPARE_STREAMS", 1);
     o.host_cache_mib = env_int("STSTHIP_HOST_CACHE_MIB", 4096);
     o.exchange_every = env_int("STSTHIP_EXCHANGE_EVERY", 0);
     o.upload_strips = env_int("STSTHIP_UPLOAD_STRIPS", 0);
@@ -158,30 +158,21 @@ struct EventPool {
     }
 };
 
-// Side streams of the pass driver (row strips advancing concurrently).  Every caller stream gets its own
-// set, created on demand under the runtime lock: two host threads (or two torch streams) that run the pass
-// driver side by side never share one.
-static std::map<hipStream_t, std::vector<hipStream_t>> &side_streams() {
-    static std::map<hipStream_t, std::vector<hipStream_t>> streams;
+// Streams of the pass driver beside the caller's own: side streams (further row strips advancing concurrently) and
+// highest-priority band streams (a band's few waves then get the wave slots that free up first instead of queueing
+// behind the pending workgroups of an interior launch).  ONE set for the whole process, shared by every caller stream
+// and host thread: the orderings a call needs are events, so calls that overlap merely serialise on these streams.
+// HIP deals streams onto a few hardware queues in creation order, idle ones included, and launches that share a
+// queue serialise -- a set per caller stream (round 2) multiplied idle streams and made a host that brings its own
+// stream collide with the set prepared for the runtime's stream (bench 6500 -> 4280, profiles/r02_short_runs.txt).
+// With one set there is nothing to multiply, so it is created AND first used at ststhip_init (a stream's first use
+// costs milliseconds, 15-20 ms for the three, which would otherwise land in the first update call).
+static std::vector<hipStream_t> &shared_side_streams() {
+    static std::vector<hipStream_t> streams;
     return streams;
 }
-static bool side_streams_for(hipStream_t caller, int n, std::vector<hipStream_t> &out) {
-    Runtime &r = rt();
-    std::lock_guard<std::mutex> guard(r.lock);
-    auto &pool = side_streams()[caller];
-    while (int(pool.size()) < n) {
-        hipStream_t extra;
-        if (hipStreamCreateWithFlags(&extra, hipStreamNonBlocking) != hipSuccess)
-            return false;
-        pool.push_back(extra);
-    }
-    out.assign(pool.begin(), pool.begin() + n);
-    return true;
-}
-// Streams for the boundary bands of row strips: highest priority, so that a band's few waves get the wave slots
-// that free up first instead of queueing behind the pending workgroups of an interior launch.
-static std::map<hipStream_t, std::vector<hipStream_t>> &band_streams() {
-    static std::map<hipStream_t, std::vector<hipStream_t>> streams;
+static std::vector<hipStream_t> &shared_band_streams() {
+    static std::vector<hipStream_t> streams;
     return streams;
 }
 static hipError_t create_band_stream(hipStream_t *stream) {
@@ -192,18 +183,68 @@ static hipError_t create_band_stream(hipStream_t *stream) {
         greatest = 0;
     return hipStreamCreateWithPriority(stream, hipStreamNonBlocking, greatest);
 }
-static bool band_streams_for(hipStream_t caller, int n, std::vector<hipStream_t> &out) {
-    Runtime &r = rt();
-    std::lock_guard<std::mutex> guard(r.lock);
-    auto &pool = band_streams()[caller];
-    while (int(pool.size()) < n) {
+// caller holds the runtime lock
+static bool grow_shared_streams(int n_side, int n_band) {
+    auto &side = shared_side_streams();
+    auto &band = shared_band_streams();
+    while (int(side.size()) < n_side) {
+        hipStream_t extra;
+        if (hipStreamCreateWithFlags(&extra, hipStreamNonBlocking) != hipSuccess)
+            return false;
+        side.push_back(extra);
+    }
+    while (int(band.size()) < n_band) {
         hipStream_t extra;
         if (create_band_stream(&extra) != hipSuccess)
             return false;
-        pool.push_back(extra);
+        band.push_back(extra);
     }
-    out.assign(pool.begin(), pool.begin() + n);
     return true;
+}
+static bool side_streams_for(hipStream_t, int n, std::vector<hipStream_t> &out) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> guard(r.lock);
+    if (!grow_shared_streams(n, 0))
+        return false;
+    out.assign(shared_side_streams().begin(), shared_side_streams().begin() + n);
+    return true;
+}
+static bool band_streams_for(hipStream_t, int n, std::vector<hipStream_t> &out) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> guard(r.lock);
+    if (!grow_shared_streams(0, n))
+        return false;
+    out.assign(shared_band_streams().begin(), shared_band_streams().begin() + n);
+    return true;
+}
+
+// Creates the shared streams (one side stream, two band streams) and uses each once: a stream's first use costs
+// milliseconds -- 25 ms for the three, which would otherwise land in the first update call (a one-shot 1000-generation
+// run of the unchanged jacobi example: Walltime 0.123 -> 0.097 s, hotspot 0.098 -> 0.068 s; profiles/r03_short_runs.txt).
+// Called when the host first asks for the runtime's own stream or for pinned host memory, i.e. when it is a host
+// that runs on the runtime's stream (the C++ templates: a Grid's host mirror is allocated before the first update).
+// NOT at ststhip_init: for a host that creates its own stream afterwards (torch) the three would sit in front of
+// it in the hardware queues' dealing order, and its sweeps measured 2-11 % slower (bench.py 6900 -> 6200).
+static void prepare_shared_streams_once() {
+    static bool done = false;
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> guard(r.lock);
+    if (done || !r.up || !opt().prepare_streams)
+        return;
+    done = true;
+    if (!grow_shared_streams(1, 2))
+        return;
+    std::vector<hipStream_t> made(shared_side_streams());
+    made.insert(made.end(), shared_band_streams().begin(), shared_band_streams().end());
+    made.push_back(r.stream);
+    void *word = nullptr;
+    if (hipMalloc(&word, 256) == hipSuccess) {
+        for (hipStream_t st : made)
+            (void)hipMemsetAsync(word, 0, 4, st);
+        for (hipStream_t st : made)
+            (void)hipStreamSynchronize(st);
+        (void)hipFree(word);
+    }
 }
 
 static std::vector<AppEntry> &apps() {
@@ -490,33 +531,6 @@ int ststhip_init(int device) {
     r.compute_units = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
     r.up = true;
-    // STSTHIP_PREPARE_STREAMS=1: the streams the pass driver adds to the runtime's own stream -- one side stream and two
-    // highest-priority band streams -- are created and used once here: a stream (and the hardware queue behind it)
-    // costs milliseconds on first use, 15-20 ms for the three, which otherwise land in the first update call (a
-    // one-shot 1000-generation run of the unchanged jacobi example: 0.121 -> 0.096 s; profiles/r02_short_runs.txt).
-    // Off by default: for a caller that brings its OWN stream (bench.py, the Python API) these would be four idle
-    // streams in front of its own on the few hardware queues, and its strips collide (bench.py 6500 -> 4280).
-    if (opt().prepare_streams) {
-        std::vector<hipStream_t> made;
-        auto &side = side_streams()[r.stream];
-        auto &band = band_streams()[r.stream];
-        hipStream_t extra = nullptr;
-        if (side.empty() && hipStreamCreateWithFlags(&extra, hipStreamNonBlocking) == hipSuccess)
-            side.push_back(extra);
-        while (band.size() < 2 && create_band_stream(&extra) == hipSuccess)
-            band.push_back(extra);
-        made.insert(made.end(), side.begin(), side.end());
-        made.insert(made.end(), band.begin(), band.end());
-        made.push_back(r.stream);
-        void *word = nullptr;
-        if (hipMalloc(&word, 256) == hipSuccess) {
-            for (hipStream_t st : made)
-                (void)hipMemsetAsync(word, 0, 4, st);
-            for (hipStream_t st : made)
-                (void)hipStreamSynchronize(st);
-            (void)hipFree(word);
-        }
-    }
     return STSTHIP_OK;
 }
 
@@ -526,18 +540,13 @@ int ststhip_shutdown(void) {
     if (!r.up)
         return STSTHIP_OK;
     (void)hipStreamSynchronize(r.stream);
-    for (auto &per_caller : side_streams())
-        for (hipStream_t extra : per_caller.second) {
+    for (auto *pool : {&shared_side_streams(), &shared_band_streams()}) {
+        for (hipStream_t extra : *pool) {
             (void)hipStreamSynchronize(extra);
             (void)hipStreamDestroy(extra);
         }
-    side_streams().clear();
-    for (auto &per_caller : band_streams())
-        for (hipStream_t extra : per_caller.second) {
-            (void)hipStreamSynchronize(extra);
-            (void)hipStreamDestroy(extra);
-        }
-    band_streams().clear();
+        pool->clear();
+    }
     for (hipEvent_t ev : EventPool::free_list())
         (void)hipEventDestroy(ev);
     EventPool::free_list().clear();
@@ -695,6 +704,7 @@ int ststhip_host_malloc(void **ptr, size_t bytes) {
         return fail(STSTHIP_ERR_INVALID, "null argument");
     if (int rc = ststhip_init(-1))
         return rc;
+    prepare_shared_streams_once();
     Runtime &r = rt();
     const std::size_t bucket = bucket_of(bytes ? bytes : 1);
     {
@@ -770,6 +780,7 @@ int ststhip_default_stream(ststhip_stream *stream) {
         return fail(STSTHIP_ERR_INVALID, "null argument");
     if (int rc = ststhip_init(-1))
         return rc;
+    prepare_shared_streams_once();
     *stream = rt().stream;
     return STSTHIP_OK;
 }

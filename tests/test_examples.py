@@ -286,3 +286,19 @@ def test_convection_kernels_bit_identical_to_cpu_backend(res, iterations):
     bits after two time steps."""
     res = run([exe("convection_bits_test"), str(res), str(iterations)])
     assert b"0 of" in res.stdout and b"differ" in res.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,iterations", [(40, 30), (128, 100), (256, 64)])
+def test_convection_kernels_on_hip_equal_the_oracle(oracle, tmp_path, res, iterations):
+    """The reference's unchanged convection kernels on stencil::hip (build/examples/convection_dump_hip: per-field
+    planes, the generic staged rule: two generations per launch on two stages) against the oracle's restatement of
+    them: two time steps of `iterations` pseudo-transient iterations + one thermal step, all eleven fp64 fields of
+    every cell as bits."""
+    exe = os.path.join(EX, "convection_dump_hip")
+    if not os.path.exists(exe):
+        pytest.fail("build/examples/convection_dump_hip missing: run __graft_entry__.build() where /root/reference exists")
+    subprocess.check_call([exe, str(res), str(iterations), str(tmp_path)], stdout=subprocess.DEVNULL)
+    differing, cells, moved = oracle.convection_dump_check(str(tmp_path), iterations)
+    assert cells == (3 * res) * res and moved > 1e-6
+    assert differing == {"round0_pt": 0, "round0_ts": 0, "round1_pt": 0, "round1_ts": 0}, differing

@@ -227,3 +227,18 @@ def test_jacobi25_oracle_against_numpy():
                 nxt[r, c] = s
         cur = nxt
     assert np.array_equal(got.view(np.uint32), cur.view(np.uint32))
+
+
+def test_convection_oracle_against_unchanged_reference_functors(oracle, tmp_path):
+    """The oracle's restatement of the two convection kernels (stencil_oracle.c: pseudo_transient_fn,
+    thermal_solver_fn) against the reference's own source (examples/convection/convection.cpp:76-242) compiled by g++
+    on this repository's stencil::cpu backend (build/examples/convection_dump_cpu): two time steps of 30 pseudo-
+    transient iterations (three sub-iterations each) and one thermal step (two), all eleven fp64 fields of every cell
+    compared as bits.  The reference's tests hold no vector for these kernels; this is what pins the restatement."""
+    exe = os.path.join(ROOT, "build", "examples", "convection_dump_cpu")
+    if not os.path.exists(exe):
+        pytest.skip("build/examples/convection_dump_cpu not built (reference tree absent)")
+    subprocess.check_call([exe, "40", "30", str(tmp_path)], stdout=subprocess.DEVNULL)
+    differing, cells, moved = oracle.convection_dump_check(str(tmp_path), 30)
+    assert cells == 120 * 40 and moved > 1e-6
+    assert differing == {"round0_pt": 0, "round0_ts": 0, "round1_pt": 0, "round1_ts": 0}, differing

@@ -91,7 +91,8 @@ def main():
             if len(starts) > warmup + steps:
                 per_step = []
                 for s in range(warmup, warmup + steps):
-                    seg = launches[starts[s]:starts[s + 1]]
+                    # (not up to the next start: after the last timed step come the verification's launches)
+                    seg = launches[starts[s]:starts[s] + int(bench.get("launches_per_step") or (starts[s + 1] - starts[s]))]
                     span = max(b for a, b, *_ in seg) - seg[0][0]
                     busy, union, cur_a, cur_b = sum(b - a for a, b, *_ in seg), 0, None, None
                     for a, b, *_ in seg:
