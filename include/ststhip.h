@@ -349,10 +349,12 @@ int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *cons
 /* ------------------------------------------------- row-strip driver (one strip per process / GPU)
  * The grid is cut into n_ranks strips of consecutive rows; every process owns one strip on its GPU and keeps it,
  * with ghost rows, in two buffer sets inside the library.  ststhip_strip_advance() is cuda::StencilUpdate::operator()
- * for the whole distributed grid: per launch of T generations it sweeps the boundary bands first, exchanges the
- * T*radius*n_subiterations ghost rows of the NEXT launch with the two neighbours on a second stream (RCCL
- * send/recv over xGMI, no collective) while the interiors run, and splits the owned rows into two sub-strips on
- * two streams like the single-GPU pass driver.  No host code between the launches of a call: a C++ (or any FFI)
+ * for the whole distributed grid.  Its launches go in groups of m = STSTHIP_EXCHANGE_EVERY (default: 4 for strips
+ * thinner than 4096 rows, else 2) with ONE exchange of m*T*radius*n_subiterations ghost rows per group (RCCL
+ * send/recv with the two neighbours over xGMI on a second stream, no collective): inside a group every launch
+ * produces the owned rows widened by the ghost depth the rest of the group still needs; the last launch of a group
+ * sweeps the rows next to the neighbours first (one band launch), hands them to the exchange for the next group, and
+ * sweeps its interior beside both.  No host code between the launches of a call: a C++ (or any FFI)
  * host calls create / upload / advance / download.  The semantics are those of one StencilUpdate on the whole
  * grid (the reference has no spatial decomposition; role model for "same interface, several devices":
  * StencilStream/monotile/StencilUpdate.hpp:166-227).
@@ -372,6 +374,11 @@ int ststhip_strip_create(const char *app, const void *tf_params, const void *hal
 /* The same strip for a sweep that is not in the registry: the launch callback and description a caller would hand to
  * ststhip_run_passes (the C++ templates instantiate the kernel for a user's transition function in their own
  * translation unit: StencilStream/hip/StripUpdate.hpp).  The buffers are the planes `desc` describes. */
+/* The `sweep` callback of a custom strip MUST honour the calling thread's row hole (ststhip_launch_row_hole): the
+ * driver sweeps both boundary bands of a strip as one launch over [first owned row, last owned row) with the interior
+ * left out as the hole, on a highest-priority stream, while another launch sweeps the interior.  Every launch that
+ * goes through the C++ templates' launcher (hip/internal/Sweep.hpp: launch_sweep) does; a callback that ignored the
+ * hole would sweep the interior twice (same values, doubled work, no band / exchange overlap). */
 int ststhip_strip_create_custom(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc, uint64_t total_rows,
                                 uint64_t width, int rank, int n_ranks, ststhip_comm comm,
                                 ststhip_exchange_fn exchange, void *exchange_ctx, ststhip_strip *strip);
