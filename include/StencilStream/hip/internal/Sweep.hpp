@@ -1049,8 +1049,9 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         throw std::range_error("the pitch must be below 2^31 elements");
     g.pitch32 = std::uint32_t(dom.pitch);
     g.iteration = iteration;
-    // measured (profiles/r01_xcd_remap.txt): 4 % fewer HBM reads, but no gain in time for these
-    // VALU-bound kernels, so the remap is off unless asked for
+    // measured (profiles/r01_xcd_remap.txt): 4 % fewer HBM reads, but no gain in time for the independent-wave
+    // kernels; with the staged kernels 0.50 -> 0.70 ms per launch (the taper's short chunks no longer come last), and
+    // column bands per XCD in chunk-major order -1 % (profiles/r03_multi_pass.txt): off unless asked for
     g.xcd_remap = opt.xcd_remap ? 1u : 0u;
     g.last_chunk_early = (out_end + SW::G > dom.global_height && opt.last_chunk_early) ? 1u : 0u;
 

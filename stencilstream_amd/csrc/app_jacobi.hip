@@ -40,15 +40,3 @@ STSTHIP_REGISTER_APP(NAME("jacobi4general"), K6, false);
 STSTHIP_REGISTER_APP(NAME("jacobi9general"), K8, false);
 #endif
 STSTHIP_REGISTER_APP(NAME("jacobi5general"), K7, false);
-#ifndef STSTHIP_FMA_FLAVOUR
-// the uniform-coefficient form of Jacobi5General (apps/jacobi.hpp); ststhip_app_run switches to it on its
-// own and picks the variant per launch: middle launches, the first, the last, the only launch of a run
-using U00 = stencil::apps::Jacobi5Uniform<false, false>;
-using U10 = stencil::apps::Jacobi5Uniform<true, false>;
-using U01 = stencil::apps::Jacobi5Uniform<false, true>;
-using U11 = stencil::apps::Jacobi5Uniform<true, true>;
-STSTHIP_REGISTER_APP("jacobi5uniform", U00, false);
-STSTHIP_REGISTER_APP("jacobi5uniform_first", U10, false);
-STSTHIP_REGISTER_APP("jacobi5uniform_last", U01, false);
-STSTHIP_REGISTER_APP("jacobi5uniform_only", U11, false);
-#endif
