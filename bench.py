@@ -144,7 +144,7 @@ def cpu_baseline(size, generations):
     binary = os.path.join(EXAMPLES, "jacobi_Jacobi5General_cpu")
     if os.path.exists(binary):
         env = dict(os.environ, OMP_NUM_THREADS=str(cores))
-        its = max(8, generations // 4)
+        its = max(8, generations * 3)  # ~10-20 s of CPU work on 16 cores (3-3.5 Gcell-updates/s)
         try:
             dt = walltime_of([binary, str(size), str(size), str(its), "/dev/null"] + [str(c) for c in COEF], env=env)
             return {
@@ -153,9 +153,10 @@ def cpu_baseline(size, generations):
                 "cores": cores,
                 "kind": "port",
                 "implementation": "this repository's stencil::cpu backend (include/StencilStream/cpu/StencilUpdate.hpp, "
-                                  "OpenMP over rows) compiled with g++ -O2 around the reference's UNCHANGED "
-                                  "examples/jacobi/jacobi.cpp + kernels.hpp; the application's own Walltime.  The "
-                                  "reference's own cpu backend needs a SYCL compiler (icpx), absent on this box",
+                                  "OpenMP over rows) compiled with g++ -O2 around the reference's UNCHANGED transition "
+                                  "function (examples/jacobi/kernels.hpp); examples/jacobi_cpu.cpp is the reference's "
+                                  "jacobi.cpp main() for the cpu backend it has no branch for; the application's own "
+                                  "Walltime.  The reference's own cpu backend needs a SYCL compiler (icpx), absent here",
                 "sample": f"Jacobi5General {size}x{size}, {its} generations, {dt:.1f} s",
             }
         except Exception:  # noqa: BLE001 -- fall through to the oracle

@@ -346,8 +346,9 @@ namespace internal {
 // waves for a thin-cell function whose default shape holds four cells per lane.  The launcher switches to it for
 // grids too small to fill the chip with the default shape (narrow_form_cells below): a launch is then the latency
 // of one wave through its warm-up rows, and narrower lanes mean more waves sharing it.  Measured, Jacobi5General
-// (profiles/r02_small_grids.txt): 256^2 26.7 -> 46.7, 512^2 92 -> 158, 1024^2 310 -> 462, 2048^2 854 -> 1025,
-// 4096^2 1830 -> 1865 Gcell-updates/s; the default shape wins from about 4600^2 on.
+// (profiles/r02_small_grids.txt, independent waves): 256^2 26.7 -> 46.7, 512^2 92 -> 158, 1024^2 310 -> 462,
+// 2048^2 854 -> 1025; with four stages (profiles/r03_small_grids.txt) 256^2 37 -> 62, 1024^2 432 -> 551, 2048^2
+// 1088 -> 1243, 3072^2 1727 -> 1422: the default shape wins from about 2500^2 (6 M cells) on.
 template <typename F> struct NarrowForm : public F {
     NarrowForm(F const &f) : F(f) {}
 };

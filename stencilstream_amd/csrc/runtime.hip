@@ -59,7 +59,7 @@ static ststhip_options read_options() {
             at = comma == std::string::npos ? text.size() : comma + 1;
         }
     }
-    o.narrow_form_kcells = env_int("STSTHIP_NARROW_FORM_KCELLS", 20000);
+    o.narrow_form_kcells = env_int("STSTHIP_NARROW_FORM_KCELLS", 6000);
     o.narrow_band_rows = env_int("STSTHIP_NARROW_BAND_ROWS", 0);
     o.skip_constant_stores = env_int("STSTHIP_SKIP_CONSTANT_STORES", 1);
     o.xcd_remap = env_int("STSTHIP_XCD_REMAP", 0);

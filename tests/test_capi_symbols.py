@@ -41,7 +41,7 @@ def test_options_come_from_the_environment_once(built_lib, monkeypatch):
 
     capi.reload_options()
     o = capi.options()
-    assert (o.narrow_form_kcells, o.n_taper, o.skip_constant_stores, o.host_cache_mib) == (20000, -1, 1, 4096)
+    assert (o.narrow_form_kcells, o.n_taper, o.skip_constant_stores, o.host_cache_mib) == (6000, -1, 1, 4096)
     monkeypatch.setenv("STSTHIP_CHUNK_ROWS", "77")
     monkeypatch.setenv("STSTHIP_TAPER", "150:2,50:4")
     monkeypatch.setenv("STSTHIP_UPLOAD_STRIPS", "3")

@@ -968,7 +968,7 @@ def test_jacobi25_radius2_bit_exact(gpu, oracle, shape):
 
 
 def test_narrow_form_equals_default_shape(gpu, oracle, monkeypatch):
-    """Grids of up to 20 M cells are swept with one cell per lane (NarrowForm, hip/internal/Sweep.hpp): the same
+    """Grids of up to 6 M cells (here: the knob set to 20 M) are swept with one cell per lane (NarrowForm, hip/internal/Sweep.hpp): the same
     bits as the default shape, for the general, the product-carrying and the Game of Life kernels."""
     import torch
 
