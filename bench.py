@@ -5,7 +5,7 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it with
 torch.distributed.run, one rank per GPU; run plainly (`python bench.py --gpus N`, no RANK in the environment) it
 starts that launcher itself as a CHILD process -- before anything has touched the GPU -- and exits with its code.
-A "step" is ONE StencilUpdate call of `--generations` generations (default 1000, BASELINE's count).  Rank 0 prints
+A "step" is ONE StencilUpdate call of `--generations` generations (default 1000, BASELINE's count: 62 launches of 16 + one of 8).  Rank 0 prints
 ONE JSON line.
 
 Metric: Gcell-updates/s = H*W*generations / time (sub-iterations not counted), the reference's definition

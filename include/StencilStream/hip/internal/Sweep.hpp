@@ -259,7 +259,9 @@ template <typename F, bool SOA> struct SweepTuning {
     // (fewest DPP moves and halo columns per cell); fatter cells want the narrowest lane that still
     // covers the radius: K = 2 for two-word AoS cells, K = 1 otherwise.
     static constexpr int pick_k() {
-        int k = (W == 1) ? 4 : ((W == 2 && !SOA) ? 2 : 1);
+        // (two-word cells on planes: K = 1 in rounds 1-2; on four stages two cells per lane win there too --
+        // HotSpot 8192^2 planes K = 1: 1750, K = 2: 1820 at T = 8, 2090 at T = 12, profiles/r03_tune_staged.txt)
+        int k = (W == 1) ? 4 : (W == 2 ? 2 : 1);
         return std::max(k, internal::ceil_pow2(R));
     }
     // Deepest power of two up to 8 generations whose window stays within 128 words per lane -- and 6 for
@@ -280,6 +282,9 @@ template <typename F, bool SOA> struct SweepTuning {
     // T = 8: 540, 4: 650, 2: 760 Gcell/s, profiles/r02_tune_radius.txt): the window is capped at 32 words there.
     static constexpr int window_limit = R >= 2 ? 32 : 128;
     static constexpr int pick_t(int k) {
+        // two-word cells with one sub-iteration (HotSpot): twelve generations on four stages of three levels
+        if (W == 2 && NS == 1 && R == 1 && nominal_window(12, k) <= window_limit && geometry_ok(12, k))
+            return 12;
         for (int t : {8, 6, 4, 2})
             if (t == 6 ? relaxed(t, k) : (nominal_window(t, k) <= window_limit && geometry_ok(t, k)))
                 return t;
@@ -358,6 +363,19 @@ template <typename F, bool SOA> constexpr int stages_for() {
         return SweepTuning<F, SOA>::stages;
     else
         return 1;
+}
+
+// SweepTuning<F, SOA>::pinned_loads (optional member, default true; staged sweeps): keep stage 0's HBM load of row
+// y + P where the source has it -- right after row y has been taken out of its registers -- instead of letting the
+// scheduler hoist the batch's loads to its top into fresh registers, which it then has to wait for at the loop's end
+// (a stage's batch is a quarter as long as an independent wave's, and so was the time a load had to arrive).
+// Measured (profiles/r03_tune_staged.txt): Jacobi5Uniform single launches 5640 -> 5770, 2048-row strip 3670 -> 3890,
+// with two strips 5760 -> 5730; HotSpot planes 2050 -> 2100.
+template <typename F, bool SOA> constexpr bool pinned_loads_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::pinned_loads; })
+        return SweepTuning<F, SOA>::pinned_loads;
+    else
+        return true;
 }
 
 template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
@@ -548,12 +566,16 @@ struct Sweep {
     // One wave = stage SG of the unit (strip, rows [ya, yb)).
     // SKIP_CONSTANTS: the target planes of F::constant_fields already hold their values (see
     // constant_plane_mask); their stores are left out
+    // (always inlined: as a called function a stage would receive the kernel's arguments through a private copy in
+    // scratch memory -- seen for large transition functions at depths of 4 and more)
     template <bool EDGE, bool SKIP_CONSTANTS, int SG>
-    STST_DEVICE static void run(Args const &a, const int lane, const int strip, const int ya, const int yb,
+    STST_DEVICE __attribute__((always_inline)) static void run(Args const &a, const int lane, const int strip, const int ya, const int yb,
                                 std::uint32_t *lds) {
         constexpr std::uint32_t skip_mask = SKIP_CONSTANTS ? constant_plane_mask<F>() : 0u;
         constexpr int L0 = SG * L; // levels below this stage
-        SweepGeometry const &g = a.geo;
+        // (read where the kernel's arguments lie: indexing the tier tables at run time must not cost a private copy)
+        SweepGeometry const &g = *(SweepGeometry const *)(const SweepGeometry __attribute__((address_space(4))) *)(
+            (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(Args, geo));
         const int x0 = strip * OW - GX + lane * K; // global column of the lane's first cell
         const int ystart = ya - G;
         const int y_load_end = yb + G < g.load_hi ? yb + G : g.load_hi;
@@ -570,6 +592,13 @@ struct Sweep {
         // writes them while the kernel runs --, so the compiler may load a value again wherever it needs it instead
         // of holding T scalar registers over the row loop (a plain global load could not be moved over the loop's
         // stores at all).
+        // The transition function is read where the kernel's arguments lie (constant address space), not through the
+        // by-value copy: a function that indexes tables of its own at run time (FDTD's render resolver: sixteen
+        // ring bounds and coefficient sets) otherwise gets a private copy of itself in scratch memory in every
+        // stage's code -- 550 bytes per lane at every depth, which the spill-free depth rule then refuses.
+        using ConstantF = const F __attribute__((address_space(4)));
+        F const &fn = *(F const *)(ConstantF *)((const char __attribute__((address_space(4))) *)
+                                                    __builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(Args, f));
         using ConstantTDV = const TDV __attribute__((address_space(4)));
         ConstantTDV *launch_tdv = a.tdv_table ? (ConstantTDV *)(a.tdv_table)
                                               : (ConstantTDV *)(__builtin_amdgcn_kernarg_segment_ptr());
@@ -628,7 +657,11 @@ struct Sweep {
                 for (int k = 0; k < K; k++)
                     cur[k] = pre[u][k];
                 if constexpr (SG == 0) {
+                    if constexpr (W > 1 && pinned_loads_for<F, SOA>())
+                        __builtin_amdgcn_sched_barrier(0);
                     load_row(y + P, pre[u]);
+                    if constexpr (W > 1 && pinned_loads_for<F, SOA>())
+                        __builtin_amdgcn_sched_barrier(0);
                     if constexpr (EDGE) {
                         const bool row_in = unsigned(y) < unsigned(g.grid_h);
 #pragma unroll
@@ -661,7 +694,7 @@ struct Sweep {
                         if constexpr (std::is_empty_v<TDV>)
                             return TDV{};
                         else if constexpr (INLINE_TDV)
-                            return a.f.get_time_dependent_value(iteration);
+                            return fn.get_time_dependent_value(iteration);
                         else
                             return launch_tdv[(level - 1) / NS];
                     }();
@@ -712,15 +745,15 @@ struct Sweep {
                                 st[sycl::id<2>(rr, cc)] = ext[rr][k + cc];
                         // a transition function may provide a form that knows its level inside the
                         // launch at compile time (used by fused forms whose first / last level differ)
-                        if constexpr (requires { a.f.template at_level<0, 1>(st); })
-                            next[k] = a.f.template at_level<level - 1, S>(st);
+                        if constexpr (requires { fn.template at_level<0, 1>(st); })
+                            next[k] = fn.template at_level<level - 1, S>(st);
                         // ... or a form for cells that are not on the rim of the grid: in a wave whose
                         // whole footprint lies inside the grid every cell that can reach the output has
                         // 0 < row < height-1 and 0 < column < width-1 at every level
-                        else if constexpr (!EDGE && requires { a.f.interior(st); })
-                            next[k] = a.f.interior(st);
+                        else if constexpr (!EDGE && requires { fn.interior(st); })
+                            next[k] = fn.interior(st);
                         else
-                            next[k] = a.f(st);
+                            next[k] = fn(st);
                         if constexpr (EDGE)
                             if (!(row_in && col_in[k]))
                                 next[k] = a.halo; // out-of-grid cells never evolve
@@ -799,8 +832,11 @@ struct Sweep {
             super_step(t, std::false_type{});
     }
 
-    template <bool SKIP_CONSTANTS = false> STST_DEVICE static void entry(Args const &a, std::uint32_t *lds) {
-        SweepGeometry const &g = a.geo;
+    template <bool SKIP_CONSTANTS = false>
+    STST_DEVICE __attribute__((always_inline)) static void entry(Args const &a, std::uint32_t *lds) {
+        // (read where the kernel's arguments lie: indexing the tier tables at run time must not cost a private copy)
+        SweepGeometry const &g = *(SweepGeometry const *)(const SweepGeometry __attribute__((address_space(4))) *)(
+            (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(Args, geo));
         const int lane = int(threadIdx.x) & (wave_size - 1);
         const int wib = int(__builtin_amdgcn_readfirstlane(threadIdx.x / wave_size));
         // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, each with its own

@@ -107,7 +107,7 @@ template <typename F, bool SOA> struct AppAdapter {
 // A transition function with an explicit pipeline shape (used to register tuning experiments and
 // hand-picked shapes next to the heuristic default).  STAGES: waves of a workgroup that share one column strip as
 // a pipeline over the levels (Sweep.hpp).  An explicit shape is launched as it is: no narrow form.
-template <typename F, int K, int T, int P, int MINW = 1, bool INTERIOR = true, int STAGES = 1>
+template <typename F, int K, int T, int P, int MINW = 1, bool INTERIOR = true, int STAGES = 1, bool PINNED = false>
 struct Shaped : public F {
     using Block = typename F::Block;
     Shaped() = default;
@@ -123,14 +123,15 @@ struct AppRegistrar {
 
 namespace stencil {
 namespace hip {
-template <typename F, int K, int T, int P, int MINW, bool INTERIOR, int STAGES, bool SOA>
-struct SweepTuning<::ststhip_detail::Shaped<F, K, T, P, MINW, INTERIOR, STAGES>, SOA> {
+template <typename F, int K, int T, int P, int MINW, bool INTERIOR, int STAGES, bool PINNED, bool SOA>
+struct SweepTuning<::ststhip_detail::Shaped<F, K, T, P, MINW, INTERIOR, STAGES, PINNED>, SOA> {
     static constexpr int cells_per_lane = K;
     static constexpr int max_generations = T;
     static constexpr int prefetch_rows = P;
     static constexpr bool interior_variant = INTERIOR;
     static constexpr int min_waves_per_simd = MINW;
     static constexpr int stages = STAGES;
+    static constexpr bool pinned_loads = PINNED;
     static constexpr bool narrow_form = false;
     // hints the wrapped function's own tuning carries
     static constexpr bool trapezoid_fill = internal::trapezoid_fill_for<F, SOA>();

@@ -165,15 +165,17 @@ template <> struct SweepTuning<apps::Jacobi<apps::JacobiVariant::General9>, fals
     static constexpr bool interior_variant = true;
     static constexpr int min_waves_per_simd = 1;
 };
-// With 5 flops per cell the kernel is HBM bound at 8 generations per launch; 12 generations per launch (launch depths
-// 12 and its halvings 6, 3, 1) on 3 cells per lane was the optimum of the independent-wave sweep
-// (profiles/r01_tune_jacobi_uniform.txt).  Round 3: four stages per column strip (three levels per wave) leave room
-// for 4 cells per lane at six waves per SIMD -- 16384^2: 5690 -> 6000 Gcell/s as single launches, 2048 x 16384 (the
-// strip of an 8-GPU run): 3190 -> 4090, 1000 x 1500: 570 -> 710 (profiles/r03_tune_staged.txt).
+// With 5 flops per cell the kernel is HBM bound at 8 generations per launch; 12 generations per launch on 3 cells per
+// lane was the optimum of the independent-wave sweep (profiles/r01_tune_jacobi_uniform.txt).  Round 3: four stages
+// per column strip leave room for 4 cells per lane at five to six waves per SIMD -- 16384^2: 5690 -> 6000 Gcell/s as
+// single launches, 2048 x 16384 (the strip of an 8-GPU run): 3190 -> 4090, 1000 x 1500: 570 -> 710 at T = 12 -- and,
+// with stage 0's loads pinned, for 16 generations per launch (four levels per stage, launch depths 16, 8, 4, 2, 1; a
+// quarter fewer HBM bytes per generation: the timed path ran at 0.69 of the HBM peak at T = 12): two strips 5730 ->
+// 5920, 2048-row strip 3950 -> 4130 (profiles/r03_tune_staged.txt).
 template <bool FirstLaunch, bool LastLaunch>
 struct SweepTuning<apps::Jacobi5Uniform<FirstLaunch, LastLaunch>, false> {
     static constexpr int cells_per_lane = 4;
-    static constexpr int max_generations = 12;
+    static constexpr int max_generations = 16;
     static constexpr int prefetch_rows = 4;
     static constexpr bool interior_variant = true;
     static constexpr int min_waves_per_simd = 1;

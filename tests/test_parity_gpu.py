@@ -1088,13 +1088,13 @@ def test_staged_sweeps_describe_themselves(gpu):
         assert capi.app_info(app).stages == stages, app
     # a wave's share of its workgroup's strip is what the drivers count waves with
     info = capi.app_info("jacobi5uniform")
-    assert info.strip_width == (64 * info.cells_per_lane - 2 * 12) // 4
+    assert info.strip_width == (64 * info.cells_per_lane - 2 * info.max_generations) // 4
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (3, 70), (37, 257), (300, 700), (1100, 2300)], ids=str)
 def test_staged_depths_and_ragged_batches(gpu, oracle, shape):
-    """Generation counts that use every compiled depth of the staged kernels (12 + 6 + 3 + 1 with four, three, three
-    and one stage; 8 + 4 + 2 + 1 with four, four, two, one) on grids whose row counts are not multiples of the batch
+    """Generation counts that use every compiled depth of the staged kernels (16 + 4 + 2 and 8 + 4 + 2 + 1 with four, four,
+    two and one stage; HotSpot's 12 + 6 + 3 + 1 with four, three, three, one) on grids whose row counts are not multiples of the batch
     length, narrower than one strip, and with halo values that differ from the cells: uniform-coefficient Jacobi,
     general Jacobi, HotSpot on planes and as AoS (two cells per lane), against the oracle bit for bit."""
     from stencilstream_amd import update as U
@@ -1102,7 +1102,7 @@ def test_staged_depths_and_ragged_batches(gpu, oracle, shape):
     rng = np.random.default_rng(shape[0] * 31 + shape[1])
     grid = rng.random(shape, dtype=np.float32)
     for coef, halo in (([0.2] * 5, 0.0), ([0.1, 0.2, 0.3, 0.25, 0.15], 0.375)):
-        for n in (22, 15):
+        for n in (22, 31):
             got = run_hip(U.jacobi("Jacobi5General", coef), grid, n, halo=np.float32(halo))
             want = oracle.jacobi("Jacobi5General", coef, grid, n, halo=halo, n_threads=8)
             assert np.array_equal(bits(got), bits(want)), f"jacobi {coef[0]} n={n}"

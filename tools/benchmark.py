@@ -44,7 +44,7 @@ APPS = {
     "jacobi": {"cell_size": 4, "n_subiters": 1, "ops": None, "generations_per_launch": 8,
                "exe": "jacobi_Jacobi5General_hip"},
     "hotspot": {"cell_size": 8, "n_subiters": 1, "ops": 15, "generations_per_launch": 8, "exe": "hotspot_hip"},
-    "fdtd": {"cell_size": 32, "n_subiters": 2, "ops": 24, "generations_per_launch": 6, "exe": "fdtd_hip"},
+    "fdtd": {"cell_size": 32, "n_subiters": 2, "ops": 24, "generations_per_launch": 8, "exe": "fdtd_hip"},
 }
 
 
