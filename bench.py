@@ -470,12 +470,20 @@ def main():
         native = not args.debug_host_exchange and os.environ.get("STSTHIP_BENCH_EXCHANGE", "native") == "native"
         comm, why = None, None
         if native and world > 1:
-            try:
-                uid = [capi.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                comm = capi.comm_create(uid[0], rank, world)
-            except Exception as e:  # noqa: BLE001
-                why = f"{type(e).__name__}: {e}"
+            # (every rank takes part in the broadcast whatever happened on rank 0: a failure there must not leave
+            # the others waiting in a collective)
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [capi.comm_unique_id()]
+                except Exception as e:  # noqa: BLE001
+                    why = f"{type(e).__name__}: {e}"
+            dist.broadcast_object_list(uid, src=0)
+            if uid[0] is not None:
+                try:
+                    comm = capi.comm_create(uid[0], rank, world)
+                except Exception as e:  # noqa: BLE001
+                    why = f"{type(e).__name__}: {e}"
             flag = torch.tensor([0 if comm is None else 1], device=device, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             native = bool(flag.item())

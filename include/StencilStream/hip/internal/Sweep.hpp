@@ -365,17 +365,19 @@ template <typename F, bool SOA> constexpr int stages_for() {
         return 1;
 }
 
-// SweepTuning<F, SOA>::pinned_loads (optional member, default true; staged sweeps): keep stage 0's HBM load of row
+// SweepTuning<F, SOA>::pinned_loads (optional member; default: cells of up to four words; staged sweeps): keep stage 0's HBM load of row
 // y + P where the source has it -- right after row y has been taken out of its registers -- instead of letting the
 // scheduler hoist the batch's loads to its top into fresh registers, which it then has to wait for at the loop's end
 // (a stage's batch is a quarter as long as an independent wave's, and so was the time a load had to arrive).
 // Measured (profiles/r03_tune_staged.txt): Jacobi5Uniform single launches 5640 -> 5770, 2048-row strip 3670 -> 3890,
-// with two strips 5760 -> 5730; HotSpot planes 2050 -> 2100.
+// with two strips 5760 -> 5730; HotSpot planes 2050 -> 2100 (same box, explicit shapes: 1981 / 2031 -> 2035 / 2069).  A fat
+// cell's row is several loads per lane already and the scheduler's own placement is the better one: FDTD two planes
+// 452 -> 459, AoS 415 -> 425 with the loads left free.
 template <typename F, bool SOA> constexpr bool pinned_loads_for() {
     if constexpr (requires { SweepTuning<F, SOA>::pinned_loads; })
         return SweepTuning<F, SOA>::pinned_loads;
     else
-        return true;
+        return cell_words<typename F::Cell, SOA>() <= 4;
 }
 
 template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
