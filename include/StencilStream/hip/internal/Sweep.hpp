@@ -380,6 +380,24 @@ template <typename F, bool SOA> constexpr bool pinned_loads_for() {
         return cell_words<typename F::Cell, SOA>() <= 4;
 }
 
+// SweepTuning<F, SOA>::tail_permille_beside / taper_beside (optional members, defaults 350 / true): the chunk model's
+// tail weight and whether the last chunks of a launch are cut shorter, for launches that run side by side with
+// others (the pass driver's row strips).  Fitted per kernel: Jacobi5Uniform 16384^2 on two strips 6375 -> 6470 with
+// 200 / false (16 chunks of ~500 rows per strip instead of 25 of 328 with a tapered end), HotSpot 8192^2 loses 14 % with
+// the same setting (profiles/r03_stage_experiments.txt).
+template <typename F, bool SOA> constexpr int tail_permille_beside_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::tail_permille_beside; })
+        return SweepTuning<F, SOA>::tail_permille_beside;
+    else
+        return 350;
+}
+template <typename F, bool SOA> constexpr bool taper_beside_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::taper_beside; })
+        return SweepTuning<F, SOA>::taper_beside;
+    else
+        return true;
+}
+
 template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
     if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })
         return SweepTuning<F, SOA>::trapezoid_fill;
@@ -924,7 +942,7 @@ inline ststhip_options const &options() { return *ststhip_get_options(); }
 // chunks waste the tail, short chunks waste warm-up rows.  (Measured optimum for Jacobi 16384^2,
 // T = 8: ~135 rows; the formula gives 133.)
 inline int pick_chunk_rows(int out_rows, unsigned n_strips, int overhead_rows, int resident_blocks,
-                           int units_per_block) {
+                           int units_per_block, int tail_permille_beside = 350) {
     ststhip_options const &opt = options();
     if (opt.chunk_rows > 0)
         return std::min(opt.chunk_rows, std::max(out_rows, 1));
@@ -936,7 +954,7 @@ inline int pick_chunk_rows(int out_rows, unsigned n_strips, int overhead_rows, i
     const double slots = double(cus) * std::max(resident_blocks, 1) * units_per_block;
     // tail weight: 0.5 for a launch that has the chip to itself; launches that run side by side (their boundary
     // bands on streams of their own) want slightly longer chunks still (profiles/r02_ab_bands_beside.txt)
-    const double alpha = (opt.tail_permille > 0 ? opt.tail_permille : (side_by_side > 1 ? 350 : 500)) / 1000.0 / side_by_side;
+    const double alpha = (opt.tail_permille > 0 ? opt.tail_permille : (side_by_side > 1 ? tail_permille_beside : 500)) / 1000.0 / side_by_side;
     const double overhead = double(overhead_rows) + 8.0;
     double rows = std::sqrt(double(out_rows) * double(n_strips) * overhead / (alpha * slots));
     rows = std::max(rows, 1.0);
@@ -960,7 +978,7 @@ inline int pick_chunk_rows(int out_rows, unsigned n_strips, int overhead_rows, i
 // Default (profiles/r01_tune_taper.txt): the last 12 % of the rows in quarter-length chunks when the
 // launch has the chip to itself (+7 % for a full-grid Jacobi launch, +2..4 % HotSpot / FDTD); launches
 // that run side by side already fill each other's ends and lose 1-6 % with shorter chunks.
-inline void plan_tiers(SweepGeometry &g, int out_rows) {
+inline void plan_tiers(SweepGeometry &g, int out_rows, bool taper_beside = true) {
     ststhip_options const &opt = options();
     g.n_tiers = 1;
     g.tier_first[0] = 0;
@@ -970,7 +988,7 @@ inline void plan_tiers(SweepGeometry &g, int out_rows) {
     int permilles[3] = {opt.taper_permille[0], opt.taper_permille[1], opt.taper_permille[2]};
     int splits[3] = {opt.taper_split[0], opt.taper_split[1], opt.taper_split[2]};
     if (n_entries < 0) { // not set in the environment
-        n_entries = 1;
+        n_entries = (ststhip_launch_concurrency() == 1 || taper_beside) ? 1 : 0;
         permilles[0] = ststhip_launch_concurrency() == 1 ? 120 : 150;
         splits[0] = ststhip_launch_concurrency() == 1 ? 4 : 2;
     }
@@ -1062,7 +1080,7 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         const int part[2] = {int(hole_begin - out_begin), int(out_end - hole_end)};
         const std::uint64_t part_begin[2] = {out_begin, hole_end};
         const int wanted = pick_chunk_rows(std::max(part[0], part[1]), g.n_strips, overhead_rows, resident_blocks,
-                                           SW::units_per_block);
+                                           SW::units_per_block, tail_permille_beside_for<F, SOA>());
         g.n_tiers = 2;
         unsigned first = 0;
         for (int t = 0; t < 2; t++) {
@@ -1080,9 +1098,9 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         g.chunk_rows = std::max(g.tier_rows[0], g.tier_rows[1]);
     } else {
         g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), g.n_strips, overhead_rows, resident_blocks,
-                                       SW::units_per_block);
+                                       SW::units_per_block, tail_permille_beside_for<F, SOA>());
         g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
-        plan_tiers(g, int(out_end - out_begin));
+        plan_tiers(g, int(out_end - out_begin), taper_beside_for<F, SOA>());
     }
     if (dom.pitch >= (1ull << 31))
         throw std::range_error("the pitch must be below 2^31 elements");

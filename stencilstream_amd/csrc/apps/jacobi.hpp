@@ -180,6 +180,9 @@ struct SweepTuning<apps::Jacobi5Uniform<FirstLaunch, LastLaunch>, false> {
     static constexpr bool interior_variant = true;
     static constexpr int min_waves_per_simd = 1;
     static constexpr int stages = 4;
+    // two row strips side by side: 16 chunks of ~500 rows per strip, no tapered end (6375 -> 6470)
+    static constexpr int tail_permille_beside = 200;
+    static constexpr bool taper_beside = false;
 };
 } // namespace hip
 } // namespace stencil
