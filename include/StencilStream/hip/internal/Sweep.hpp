@@ -949,9 +949,15 @@ inline ststhip_options const &options() { return *ststhip_get_options(); }
 // with units = strips * out_rows / rows.  Minimising over rows gives the closed form below: long
 // chunks waste the tail, short chunks waste warm-up rows.  (Measured optimum for Jacobi 16384^2,
 // T = 8: ~135 rows; the formula gives 133.)
+// `tail_permille_beside` (a kernel's own weight for launches that run side by side, SweepTuning) replaces the general
+// 350 only where the general rule already gives the launch well over one residency round of units: with fewer, longer
+// chunks leave part of the chip without a unit (uniform Jacobi form, 200 against 350: 16384^2 +1.4 %, 24576^2 +1.2 %,
+// but 8192^2 -11 %, 6144^2 -12 %: profiles/r03_stage_experiments.txt).  *kernel_rule says which one was taken.
 inline int pick_chunk_rows(int out_rows, unsigned n_strips, int overhead_rows, int resident_blocks,
-                           int units_per_block, int tail_permille_beside = 350) {
+                           int units_per_block, int tail_permille_beside = 350, bool *kernel_rule = nullptr) {
     ststhip_options const &opt = options();
+    if (kernel_rule)
+        *kernel_rule = false;
     if (opt.chunk_rows > 0)
         return std::min(opt.chunk_rows, std::max(out_rows, 1));
     int cus = 256;
@@ -962,11 +968,19 @@ inline int pick_chunk_rows(int out_rows, unsigned n_strips, int overhead_rows, i
     const double slots = double(cus) * std::max(resident_blocks, 1) * units_per_block;
     // tail weight: 0.5 for a launch that has the chip to itself; launches that run side by side (their boundary
     // bands on streams of their own) want slightly longer chunks still (profiles/r02_ab_bands_beside.txt)
-    const double alpha = (opt.tail_permille > 0 ? opt.tail_permille : (side_by_side > 1 ? tail_permille_beside : 500)) / 1000.0 / side_by_side;
+    double alpha = (opt.tail_permille > 0 ? opt.tail_permille : (side_by_side > 1 ? 350 : 500)) / 1000.0 / side_by_side;
     const double overhead = double(overhead_rows) + 8.0;
     double rows = std::sqrt(double(out_rows) * double(n_strips) * overhead / (alpha * slots));
     rows = std::max(rows, 1.0);
     long chunks = std::max<long>(1, long(double(out_rows) / rows + 0.5));
+    if (opt.tail_permille <= 0 && side_by_side > 1 && tail_permille_beside != 350 &&
+        double(chunks) * n_strips / slots >= 1.2) {
+        alpha = tail_permille_beside / 1000.0 / side_by_side;
+        rows = std::max(std::sqrt(double(out_rows) * double(n_strips) * overhead / (alpha * slots)), 1.0);
+        chunks = std::max<long>(1, long(double(out_rows) / rows + 0.5));
+        if (kernel_rule)
+            *kernel_rule = true;
+    }
     // snap to a whole number of residency rounds (just below it) when that is a small change:
     // a launch of k*S + a few units pays for a nearly empty extra round
     const double rounds = double(chunks) * n_strips / slots;
@@ -1088,7 +1102,7 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         const int part[2] = {int(hole_begin - out_begin), int(out_end - hole_end)};
         const std::uint64_t part_begin[2] = {out_begin, hole_end};
         const int wanted = pick_chunk_rows(std::max(part[0], part[1]), g.n_strips, overhead_rows, resident_blocks,
-                                           SW::units_per_block, tail_permille_beside_for<F, SOA>());
+                                           SW::units_per_block);
         g.n_tiers = 2;
         unsigned first = 0;
         for (int t = 0; t < 2; t++) {
@@ -1105,10 +1119,11 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
         g.n_chunks = first;
         g.chunk_rows = std::max(g.tier_rows[0], g.tier_rows[1]);
     } else {
+        bool kernel_rule = false;
         g.chunk_rows = pick_chunk_rows(int(out_end - out_begin), g.n_strips, overhead_rows, resident_blocks,
-                                       SW::units_per_block, tail_permille_beside_for<F, SOA>());
+                                       SW::units_per_block, tail_permille_beside_for<F, SOA>(), &kernel_rule);
         g.n_chunks = unsigned((out_end - out_begin + g.chunk_rows - 1) / g.chunk_rows);
-        plan_tiers(g, int(out_end - out_begin), taper_beside_for<F, SOA>());
+        plan_tiers(g, int(out_end - out_begin), !kernel_rule || taper_beside_for<F, SOA>());
     }
     if (dom.pitch >= (1ull << 31))
         throw std::range_error("the pitch must be below 2^31 elements");
