@@ -31,10 +31,18 @@ template <typename Cell> class Grid {
         void *device = nullptr;
         bool host_valid = false;
         bool device_valid = false;
+        // an upload queued by start_upload() that the host has not waited for yet: the pinned mirror must not be
+        // written (or freed) before it has been read
+        ststhip_event upload_event = nullptr;
+        bool upload_pending = false;
 
         explicit Storage(sycl::range<2> extent) : extent(extent) {}
         Storage(Storage const &) = delete;
         ~Storage() {
+            if (upload_pending)
+                ststhip_event_synchronize(upload_event);
+            if (upload_event)
+                ststhip_event_destroy(upload_event);
             if (host)
                 ststhip_host_free(host);
             if (device)
@@ -68,17 +76,31 @@ template <typename Cell> class Grid {
             }
             host_valid = true;
         }
-        void sync_to_device() {
+        void wait_upload() {
+            if (upload_pending) {
+                internal::check(ststhip_event_synchronize(upload_event), "grid upload");
+                upload_pending = false;
+            }
+        }
+        // The device copy is up to date for work queued on `s` after this call; the host does not wait for the
+        // transfer (allocating the buffers of the update that follows takes as long as a good part of it).
+        void start_upload(ststhip_stream s) {
             need_device();
             if (!device_valid) {
                 need_host();
-                ststhip_stream s = internal::default_stream();
                 internal::check(ststhip_memcpy_h2d(device, host, bytes(), s), "grid upload");
-                // the pinned mirror may be rewritten by the host right after this call
-                internal::check(ststhip_stream_synchronize(s), "grid upload");
+                if (!upload_event)
+                    internal::check(ststhip_event_create(&upload_event), "grid upload");
+                internal::check(ststhip_event_record(upload_event, s), "grid upload");
+                upload_pending = true;
                 host_valid = true;
             }
             device_valid = true;
+        }
+        // ... and for any stream, and the pinned mirror may be rewritten by the host right after this call
+        void sync_to_device() {
+            start_upload(internal::default_stream());
+            wait_upload();
         }
     };
 
@@ -94,6 +116,7 @@ template <typename Cell> class Grid {
 
     void copy_from_buffer(sycl::buffer<Cell, 2> source) {
         require_same_extent(source.get_range());
+        storage->wait_upload();
         storage->need_host(/*overwritten=*/true);
         std::memcpy(static_cast<void *>(storage->host), source.data(), storage->bytes());
         storage->host_valid = true;
@@ -114,8 +137,10 @@ template <typename Cell> class Grid {
       public:
         GridAccessor(Grid &grid) : keep_alive(grid.storage), width(grid.get_grid_width()) {
             keep_alive->sync_to_host();
-            if constexpr (!read_only)
+            if constexpr (!read_only) {
+                keep_alive->wait_upload(); // the mirror is about to be written
                 keep_alive->device_valid = false;
+            }
             cells = keep_alive->host;
         }
         Ref operator[](sycl::id<2> at) const { return cells[at[0] * width + at[1]]; }
@@ -141,8 +166,14 @@ template <typename Cell> class Grid {
         storage->sync_to_device();
         return static_cast<Cell const *>(storage->device);
     }
+    // The same for work queued on `stream` after this call: the upload is queued there and not waited for.
+    Cell const *device_cells_on(ststhip_stream stream) {
+        storage->start_upload(stream);
+        return static_cast<Cell const *>(storage->device);
+    }
     // AoS cells in HBM about to be overwritten completely by a kernel on the runtime's stream.
     Cell *device_cells_for_overwrite() {
+        storage->wait_upload();
         storage->need_device();
         storage->device_valid = true;
         storage->host_valid = false;

@@ -258,7 +258,9 @@ class StencilUpdate {
         ststhip_domain dom = domain_of(source_grid);
         GridImpl result = source_grid.make_similar();
         Planes from, to;
-        from.plane[0] = const_cast<Cell *>(source_grid.device_cells());
+        // (the upload is queued in front of the sweeps and not waited for: the result grid and the pass driver's swap
+        // buffer are allocated while it runs)
+        from.plane[0] = const_cast<Cell *>(source_grid.device_cells_on(stream));
         to.plane[0] = result.device_cells_for_overwrite();
         run_passes(dom, from, to, stream);
         return result;
@@ -275,12 +277,14 @@ class StencilUpdate {
             offsets[f] = Planes::elem_offset(f);
             sizes[f] = Planes::elem_size(f);
         }
+        // (queued first and not waited for: the planes are allocated while the cells are on their way)
+        Cell const *cells = source_grid.device_cells_on(stream);
         Planes sets[2];
         for (auto &set : sets)
             for (int f = 0; f < n; f++)
                 set.plane[f] = internal::device_alloc_on(n_cells * sizes[f], stream);
 
-        internal::check(ststhip_scatter_fields(source_grid.device_cells(), sizeof(Cell), n_cells, n,
+        internal::check(ststhip_scatter_fields(cells, sizeof(Cell), n_cells, n,
                                                offsets, sizes, sets[0].plane, stream),
                         "scatter");
         run_passes(dom, sets[0], sets[1], stream); // n_iterations == 0 copies the planes

@@ -169,7 +169,7 @@ typedef struct {
     int32_t host_cache_mib;        /* free pinned host blocks kept for reuse                              */
     int32_t reserved0;
     int32_t exchange_every;        /* strip driver: exchange m*g ghost rows every m-th launch; 0/1 = every launch */
-    int32_t upload_strips;         /* hip::Grid upload in this many row strips overlapped with the first pass; 0 = rule */
+    int32_t reserved1;
     int32_t reserved[6];
 } ststhip_options;
 const ststhip_options *ststhip_get_options(void);

@@ -133,7 +133,7 @@ class Options(C.Structure):
                    "max_generations", "allow_spilling_depths", "virtual_strips", "two_strips_permille",
                    "two_strips_permille_outer", "strip_skew_permille", "bands_beside_interior", "band_stream_priority",
                    "bands_apart", "bands_one_launch", "comm_stream_priority", "jacobi_fastpath", "conway_fastpath",
-                   "prepare_streams", "host_cache_mib", "reserved0", "exchange_every", "upload_strips")] + \
+                   "prepare_streams", "host_cache_mib", "reserved0", "exchange_every", "reserved1")] + \
                [("reserved", C.c_int32 * 6)]
 
 

@@ -80,7 +80,6 @@ static ststhip_options read_options() {
     o.prepare_streams = env_int("STSTHIP_PREPARE_STREAMS", 1);
     o.host_cache_mib = env_int("STSTHIP_HOST_CACHE_MIB", 4096);
     o.exchange_every = env_int("STSTHIP_EXCHANGE_EVERY", 0);
-    o.upload_strips = env_int("STSTHIP_UPLOAD_STRIPS", 0);
     return o;
 }
 static ststhip_options &options_storage() {

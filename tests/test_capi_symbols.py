@@ -44,15 +44,15 @@ def test_options_come_from_the_environment_once(built_lib, monkeypatch):
     assert (o.narrow_form_kcells, o.n_taper, o.skip_constant_stores, o.host_cache_mib) == (6000, -1, 1, 4096)
     monkeypatch.setenv("STSTHIP_CHUNK_ROWS", "77")
     monkeypatch.setenv("STSTHIP_TAPER", "150:2,50:4")
-    monkeypatch.setenv("STSTHIP_UPLOAD_STRIPS", "3")
+    monkeypatch.setenv("STSTHIP_EXCHANGE_EVERY", "3")
     assert capi.options().chunk_rows == 0  # not re-read behind the host's back
     capi.reload_options()
     o = capi.options()
     assert o.chunk_rows == 77 and o.n_taper == 2 and list(o.taper_permille)[:2] == [150, 50] and list(o.taper_split)[:2] == [2, 4]
-    assert o.upload_strips == 3
+    assert o.exchange_every == 3
     monkeypatch.delenv("STSTHIP_CHUNK_ROWS")
     monkeypatch.delenv("STSTHIP_TAPER")
-    monkeypatch.delenv("STSTHIP_UPLOAD_STRIPS")
+    monkeypatch.delenv("STSTHIP_EXCHANGE_EVERY")
     capi.reload_options()
     assert capi.options().chunk_rows == 0
 

@@ -28,6 +28,18 @@ def test_hip_api():
 
 
 @pytest.mark.gpu
+def test_grid_upload_does_not_block_and_host_writes_wait_for_it():
+    """tests/cpp/grid_upload_test.hip: hip::Grid queues its upload in front of the update and returns; a write
+    accessor, copy_from_buffer and the grid's destruction wait for it."""
+    binary = os.path.join(OUT, "grid_upload_test")
+    if not os.path.exists(binary):
+        pytest.fail("build/tests/grid_upload_test missing: run __graft_entry__.build()")
+    res = subprocess.run([binary], capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stdout.decode() + res.stderr.decode()
+    assert b"0 failures" in res.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ranks", [2, 3])
 def test_strip_driver_from_a_plain_cpp_host(ranks):
     """tests/cpp/strip_host_test.cpp: a g++-built C++ program (no Python, no torch, no HIP headers) forks `ranks`
