@@ -244,6 +244,22 @@ static void prepare_shared_streams_once() {
             (void)hipStreamSynchronize(st);
         (void)hipFree(word);
     }
+    // ... and the copy engines: the first copy of a megabyte or more between pinned host memory and the device takes
+    // 7.4 ms longer than any later one, whatever its size and buffers (tools/debug/malloc_time.py: 1 GiB 25.9 ms, then
+    // 18.7 ms; a 4 KiB copy does not take that path).  One megabyte each way on the runtime's stream, here, instead of
+    // inside the first grid's upload and the first result's download.
+    constexpr std::size_t probe = 1 << 20;
+    void *host = nullptr, *device = nullptr;
+    if (hipHostMalloc(&host, probe, hipHostMallocDefault) == hipSuccess && hipMalloc(&device, probe) == hipSuccess) {
+        std::memset(host, 0, probe);
+        (void)hipMemcpyAsync(device, host, probe, hipMemcpyHostToDevice, r.stream);
+        (void)hipMemcpyAsync(host, device, probe, hipMemcpyDeviceToHost, r.stream);
+        (void)hipStreamSynchronize(r.stream);
+    }
+    if (device)
+        (void)hipFree(device);
+    if (host)
+        (void)hipHostFree(host);
 }
 
 static std::vector<AppEntry> &apps() {
