@@ -664,6 +664,9 @@ struct Sweep {
         if constexpr (SG == 0)
             static_for<0, P>([&](auto u) __attribute__((always_inline)) { load_row(ystart + u, pre[u]); });
 
+        // the levels that are not due yet are skipped while the pipeline fills (check-free waves only)
+        constexpr bool TRAPEZOID = !EDGE && trapezoid_fill_for<F, SOA>();
+
         // One input row through this stage's levels.  `step` counts the rows fed to level 1 of the unit; the row this
         // stage receives at `step` is what level L0 emitted for it.  While the pipeline fills (FILLING) level l only
         // has to produce rows from step 2*l*R on -- earlier outputs cannot reach a stored row -- so the deeper levels
@@ -751,18 +754,25 @@ struct Sweep {
                         // -- and positive: a cell that can reach a stored row has 0 < row < height-1 and 0 < column <
                         // width-1 at every level there (the footprint lies inside the grid and a level-l cell that
                         // matters lies l*R cells inside the footprint), so a transition function's own tests for the
-                        // first row and column fold away; cells nearer the footprint's border are computed on a wrong
-                        // premise and never read.  (The upper bounds are true as well and fold the tests for the last
+                        // first row and column fold away.  (The upper bounds are true as well and fold the tests for the last
                         // row and column -- the unchanged HotSpot example 0.061 -> 0.056 s with all four --, but as
                         // relations between two variables they cost the optimiser dearly: the self-checking function
                         // of the reference's tests compiles in 150 s without them and not within 15 minutes with them.)
+                        // Both statements are TRUE wherever they are made: x0 + k >= the footprint's first column,
+                        // which is positive in a check-free wave (entry()); the row is positive at every level a
+                        // trapezoid fill computes (a level is due from step 2*level*R on, so j >= level*R), and a
+                        // kernel without the trapezoid hands never-read warm-up cells row max(j, 1) instead of a
+                        // negative one (one scalar instruction per level and row).
+                        int row_id = j;
                         if constexpr (!EDGE) {
-                            __builtin_assume(j > 0);
+                            if constexpr (!TRAPEZOID)
+                                row_id = j > 1 ? j : 1;
+                            __builtin_assume(row_id > 0);
                             __builtin_assume(x0 + k > 0);
                         }
                         __builtin_assume(g.grid_h >= 0);
                         __builtin_assume(g.grid_w >= 0);
-                        StencilImpl st(sycl::id<2>(std::size_t(std::int64_t(j)),
+                        StencilImpl st(sycl::id<2>(std::size_t(std::int64_t(row_id)),
                                                    std::size_t(std::int64_t(x0 + k))),
                                        sycl::range<2>(std::size_t(g.grid_h), std::size_t(g.grid_w)),
                                        iteration, subiteration, tdv);
@@ -818,7 +828,6 @@ struct Sweep {
 
         // Super-step t: stage SG works on batch t - SG (rows [b*P, (b+1)*P) of the unit's feed).  Every wave of the
         // workgroup passes the same number of barriers, whether it has a batch in this super-step or not.
-        constexpr bool TRAPEZOID = !EDGE && trapezoid_fill_for<F, SOA>();
         // batches before this one hold nothing this stage needs: its first level is due from step 2*(L0+1)*R on and
         // reads window rows from 2R steps before that
         constexpr int first_batch = TRAPEZOID ? (2 * L0 * R) / P : 0;
@@ -899,8 +908,9 @@ struct Sweep {
         yb = yb < g.out_end ? yb : g.out_end;
 
         const int xw0 = strip * OW - GX; // footprint of the unit
+        // (xw0 > 0, not >= 0: the check-free code tells the transition function that its column is positive)
         const bool interior =
-            INTERIOR_VARIANT && xw0 >= 0 && xw0 + LW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
+            INTERIOR_VARIANT && xw0 > 0 && xw0 + LW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
         // the stage of a wave is a compile-time property of the code it runs (levels, iteration and sub-iteration
         // indices, fused forms): one instantiation per stage, selected by the wave's index in the workgroup
         static_for<0, W>([&](auto sg) __attribute__((always_inline)) {

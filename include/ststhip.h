@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STSTHIP_ABI_VERSION 4
+#define STSTHIP_ABI_VERSION 5
 
 typedef enum {
     STSTHIP_OK = 0,
@@ -338,9 +338,17 @@ int ststhip_comm_unique_id(unsigned char id[STSTHIP_COMM_ID_BYTES]);
 int ststhip_comm_create(const unsigned char id[STSTHIP_COMM_ID_BYTES], int rank, int n_ranks,
                         ststhip_comm *comm);
 int ststhip_comm_destroy(ststhip_comm comm);
-/* For every plane p: send `n_rows` rows starting at send_up[p] to rank-1 and at send_down[p] to
- * rank+1, receive into recv_up[p] (from rank-1) and recv_down[p] (from rank+1).  row_bytes[p] =
- * bytes of one row of plane p.  Ranks at the ends skip the missing neighbour. */
+/* The ranks this rank exchanges ghost rows with: `up` holds the rows above its own, `down` the rows below; -1 = no
+ * neighbour on that side.  Default after ststhip_comm_create: a chain, rank-1 above and rank+1 below.  Other wirings
+ * are for hosts whose strips are not numbered like their ranks (meshes), for rings -- both sides may name the same
+ * rank, the messages are posted so that its upper rows arrive below and its lower rows above -- and for a rank that
+ * names ITSELF on both sides: a self send/receive inside one group is legal in RCCL, which lets one GPU run the whole
+ * exchange path (dlopen'ed symbols, byte counts, pointer arithmetic, stream order) without a second device. */
+int ststhip_comm_set_neighbours(ststhip_comm comm, int up, int down);
+int ststhip_comm_neighbours(ststhip_comm comm, int *up, int *down);
+/* For every plane p: send `n_rows` rows starting at send_up[p] to the upper neighbour (rank-1 unless set otherwise)
+ * and at send_down[p] to the lower one (rank+1), receive into recv_up[p] (from the upper neighbour) and recv_down[p]
+ * (from the lower one).  row_bytes[p] = bytes of one row of plane p.  Ranks without a neighbour on a side skip it. */
 int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *const *send_up,
                                const void *const *send_down, void *const *recv_up,
                                void *const *recv_down, const size_t *row_bytes, size_t n_rows,

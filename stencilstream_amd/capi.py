@@ -213,6 +213,8 @@ def load():
         "ststhip_comm_unique_id": [C.c_char_p],
         "ststhip_comm_create": [C.c_char_p, C.c_int, C.c_int, pp],
         "ststhip_comm_destroy": [vp],
+        "ststhip_comm_set_neighbours": [vp, C.c_int, C.c_int],
+        "ststhip_comm_neighbours": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "ststhip_comm_exchange_rows": [vp, C.c_int, pp, pp, pp, pp, C.POINTER(sz), sz, vp],
         "ststhip_strip_create": [C.c_char_p, vp, vp, u64, u64, C.c_int, C.c_int, vp, vp, vp, pp],
         "ststhip_strip_create_custom": [vp, vp, vp, u64, u64, C.c_int, C.c_int, vp, vp, vp, pp],
@@ -409,6 +411,30 @@ def comm_create(unique_id, rank, n_ranks):
     check(load().ststhip_comm_create(C.create_string_buffer(unique_id, COMM_ID_BYTES), rank, n_ranks, C.byref(comm)),
           "ststhip_comm_create")
     return comm
+
+
+def comm_destroy(comm):
+    check(load().ststhip_comm_destroy(comm), "ststhip_comm_destroy")
+
+
+def comm_set_neighbours(comm, up, down):
+    """Ranks the ghost rows are exchanged with (-1: none); both may name the same rank, or the rank itself."""
+    check(load().ststhip_comm_set_neighbours(comm, int(up), int(down)), "ststhip_comm_set_neighbours")
+
+
+def comm_neighbours(comm):
+    up, down = C.c_int(), C.c_int()
+    check(load().ststhip_comm_neighbours(comm, C.byref(up), C.byref(down)), "ststhip_comm_neighbours")
+    return up.value, down.value
+
+
+def comm_exchange_rows(comm, send_up, send_down, recv_up, recv_down, row_bytes, n_rows, stream=0):
+    """ststhip_comm_exchange_rows on device pointers (one list entry per plane)."""
+    n = len(row_bytes)
+    rb = (C.c_size_t * n)(*[int(b) for b in row_bytes])
+    check(load().ststhip_comm_exchange_rows(comm, n, _ptr_array(send_up), _ptr_array(send_down), _ptr_array(recv_up),
+                                            _ptr_array(recv_down), rb, int(n_rows), C.c_void_p(int(stream) or None)),
+          "ststhip_comm_exchange_rows")
 
 
 class Strip:

@@ -508,6 +508,7 @@ static int nccl_fail(int code, const char *what) {
 struct Comm {
     void *nccl = nullptr;
     int rank = 0, n_ranks = 1;
+    int up = -1, down = -1; // ranks the ghost rows are exchanged with (-1: none); a chain of strips by default
 };
 
 } // namespace ststhip_detail
@@ -1570,6 +1571,8 @@ int ststhip_comm_create(const unsigned char id[STSTHIP_COMM_ID_BYTES], int rank,
     Comm *c = new Comm;
     c->rank = rank;
     c->n_ranks = n_ranks;
+    c->up = rank - 1; // -1 for the first strip
+    c->down = rank + 1 < n_ranks ? rank + 1 : -1;
     int rc = rccl().CommInitRank(&c->nccl, n_ranks, uid, rank);
     if (rc != 0) {
         delete c;
@@ -1589,6 +1592,26 @@ int ststhip_comm_destroy(ststhip_comm comm) {
     return STSTHIP_OK;
 }
 
+int ststhip_comm_set_neighbours(ststhip_comm comm, int up, int down) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c || up < -1 || down < -1 || up >= c->n_ranks || down >= c->n_ranks)
+        return fail(STSTHIP_ERR_INVALID, "neighbours must be ranks of the communicator, or -1");
+    c->up = up;
+    c->down = down;
+    return STSTHIP_OK;
+}
+
+int ststhip_comm_neighbours(ststhip_comm comm, int *up, int *down) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (up)
+        *up = c->up;
+    if (down)
+        *down = c->down;
+    return STSTHIP_OK;
+}
+
 int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *const *send_up,
                                const void *const *send_down, void *const *recv_up,
                                void *const *recv_down, const size_t *row_bytes, size_t n_rows,
@@ -1600,20 +1623,39 @@ int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *cons
         return STSTHIP_OK;
     hipStream_t s = resolve(stream);
     const int ncclChar = 0;
-    const bool has_up = c->rank > 0, has_down = c->rank + 1 < c->n_ranks;
+    const bool has_up = c->up >= 0, has_down = c->down >= 0;
+    if ((has_up && (!send_up || !recv_up)) || (has_down && (!send_down || !recv_down)))
+        return fail(STSTHIP_ERR_INVALID, "bad exchange arguments");
+    // RCCL matches the messages between two ranks in the order they were posted.  Per plane: both sends, then the
+    // receive from below, then the one from above -- so that when `up` and `down` name the SAME rank (two strips of
+    // a ring, or a rank that is its own neighbour: the one-GPU loopback of tests/test_strip_native_gpu.py) that
+    // rank's upper rows land in the ghost rows below the receiver's and its lower rows in those above.  In a chain
+    // two ranks share one message per plane and direction and any order would do.
     NCCL_TRY(rccl().GroupStart());
-    for (int p = 0; p < n_planes; p++) {
+    int failed = 0; // a group that was opened is closed again whatever happens inside
+    const char *what = "";
+    auto post = [&](int code, const char *call) {
+        if (code != 0 && failed == 0) {
+            failed = code;
+            what = call;
+        }
+    };
+    for (int p = 0; p < n_planes && failed == 0; p++) {
         const size_t bytes = row_bytes[p] * n_rows;
-        if (has_up) {
-            NCCL_TRY(rccl().Send(send_up[p], bytes, ncclChar, c->rank - 1, c->nccl, s));
-            NCCL_TRY(rccl().Recv(recv_up[p], bytes, ncclChar, c->rank - 1, c->nccl, s));
-        }
-        if (has_down) {
-            NCCL_TRY(rccl().Send(send_down[p], bytes, ncclChar, c->rank + 1, c->nccl, s));
-            NCCL_TRY(rccl().Recv(recv_down[p], bytes, ncclChar, c->rank + 1, c->nccl, s));
-        }
+        if (has_up)
+            post(rccl().Send(send_up[p], bytes, ncclChar, c->up, c->nccl, s), "ncclSend (up)");
+        if (has_down)
+            post(rccl().Send(send_down[p], bytes, ncclChar, c->down, c->nccl, s), "ncclSend (down)");
+        if (has_down)
+            post(rccl().Recv(recv_down[p], bytes, ncclChar, c->down, c->nccl, s), "ncclRecv (down)");
+        if (has_up)
+            post(rccl().Recv(recv_up[p], bytes, ncclChar, c->up, c->nccl, s), "ncclRecv (up)");
     }
-    NCCL_TRY(rccl().GroupEnd());
+    const int ended = rccl().GroupEnd();
+    if (failed != 0)
+        return nccl_fail(failed, what);
+    if (ended != 0)
+        return nccl_fail(ended, "ncclGroupEnd");
     return STSTHIP_OK;
 }
 

@@ -605,8 +605,9 @@ def test_conway_full_size_word_form(gpu, oracle, monkeypatch):
 
 
 def test_baseline_size_properties(gpu, oracle):
-    """BASELINE config 1 size (Jacobi5General 16384^2): (1) temporal blocking is invisible -- the
-    8-generations-per-launch path equals the 1-generation-per-launch path bit for bit; (2) windows of the
+    """BASELINE config 1 size (Jacobi5General 16384^2, distinct coefficients: the general kernel at its compiled
+    depth, SweepTuning's max_generations): (1) temporal blocking is invisible -- the default path (two launches of the
+    deepest depth on two row strips) equals the 1-generation-per-launch path bit for bit; (2) windows of the
     result (grid corners, edges, interior, the rim of the initial square) equal the oracle run on the
     window plus a margin of n cells (cells further than n from the window border cannot be influenced
     by what lies outside it)."""
@@ -629,8 +630,8 @@ def test_baseline_size_properties(gpu, oracle):
     torch.cuda.synchronize()
     capi.app_run("jacobi5general", p, halo, dom, [src.data_ptr()], [deep.data_ptr()], 0, n, blocking=True,
                  stream=s.cuda_stream)
-    # reference run: one generation per launch, one strip (the default run above used 8 generations per
-    # launch and two row strips on two streams)
+    # reference run: one generation per launch, one strip (the default run above used the deepest compiled depth
+    # and two row strips on two streams)
     os.environ["STSTHIP_MAX_GENERATIONS"] = "1"
     os.environ["STSTHIP_VIRTUAL_STRIPS"] = "1"
     try:
@@ -658,14 +659,14 @@ def test_baseline_size_properties(gpu, oracle):
 def test_largest_baseline_grid_windows(gpu, oracle):
     """BASELINE config 5 grid size, Jacobi5General 65536^2 (2^32 cells, 16 GiB per buffer) on one GPU:
     element offsets exceed 32 bits.  Windows at the far corners / edges and inside must equal the oracle on
-    the window plus a margin of n cells; the uniform-coefficient path (product-carrying kernels, 12
-    generations per launch, two row strips) must equal the general kernel fed with the same coefficients
-    through STSTHIP_JACOBI_FASTPATH=0 on sampled windows."""
+    the window plus a margin of n cells; the uniform-coefficient path (product-carrying kernels at their compiled
+    depth -- 16 generations per launch --, two row strips) must equal the general kernel fed with the same
+    coefficients through STSTHIP_JACOBI_FASTPATH=0, checksum of per-slab checksums."""
     import torch
 
     from stencilstream_amd import capi
 
-    N, n = 65536, 25  # depths 12 + 12 + 1 (uniform) and 8 + 8 + 8 + 1 (general)
+    N, n = 65536, 25  # depths 16 + 8 + 1 (uniform) and 8 + 8 + 8 + 1 (general)
     free, _total = torch.cuda.mem_get_info()
     if free < 60 * 2 ** 30:
         pytest.skip("needs 3 x 16 GiB of HBM")
@@ -1154,6 +1155,33 @@ def test_staged_sweep_race_screen(gpu):
     for trial in range(12):
         got = run_jacobi(capi, s, "jacobi5general", q, temp, 240)
         assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"jacobi, trial {trial}"
+
+
+def test_staged_sweep_race_screen_headline_kernel(gpu):
+    """The same screen for the kernel bench.py times: the uniform-coefficient form of Jacobi5General, sixteen
+    generations per launch on four stages of four levels -- the deepest pipeline per stage in the library -- at the
+    headline size 16384^2 with random data.  240 generations = the `_first` kernel, thirteen launches of the middle one
+    and the `_last` one (two row strips with their bands side by side, as in the timed path); 16 generations = the
+    `_only` kernel.  Sixteen runs each must equal, bit for bit, the independent-wave general-coefficient kernel (no
+    stages, no LDS, nine flops per cell, eight generations per launch) on the same input."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    s = torch.cuda.Stream()
+    H = W = 16384
+    grid = torch.rand(H, W, device=gpu, generator=torch.Generator(device="cuda").manual_seed(16))
+    q = capi.JacobiParams()
+    for i in range(5):
+        q.coef[i] = 0.2
+    assert capi.app_info("jacobi5uniform").max_generations == 16 and capi.app_info("jacobi5uniform").stages == 4
+    for n, trials in ((240, 16), (16, 16), (250, 4)):  # 250 = 15 x 16 + 8 + 2: the halved depths as well
+        want = run_jacobi(capi, s, "jacobi5general_independent", q, grid, n)
+        for trial in range(trials):
+            got = run_jacobi(capi, s, "jacobi5general", q, grid, n)  # five equal coefficients: the uniform form
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), f"{n} generations, trial {trial}"
+        del want, got
 
 
 def run_jacobi(capi, stream, app, params, grid, n):

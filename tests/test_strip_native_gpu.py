@@ -206,3 +206,168 @@ def test_strips_over_rccl_on_several_gpus(gpu, oracle, tmp_path):
     want = oracle.jacobi("Jacobi5General", [0.2] * 5, grid, 49, halo=0.0, n_threads=8)
     got = np.concatenate([np.load(tmp_path / f"rccl{r}.npy") for r in range(world)], axis=0)
     assert np.array_equal(bits(got), bits(want))
+
+
+# ------------------------------------------------------------------ the RCCL exchange path on ONE GPU
+# RCCL cannot join two ranks on one device, and the pool's boxes have one: with the default chain wiring a one-rank
+# communicator posts nothing.  A rank may however name ITSELF as both neighbours (ststhip_comm_set_neighbours): a self
+# send / receive inside one group is legal, and it runs everything a two-GPU exchange runs on this side of the wire --
+# the dlopen'ed ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, the ncclChar byte counts, the pointer arithmetic
+# of the strip driver's exchange, the stream order between bands, exchange and interior.  The rank's upper rows arrive
+# in its ghost rows BELOW and its lower rows in those ABOVE: the strip is a ring of one, i.e. periodic in the rows.
+
+
+def _loopback_comm():
+    from stencilstream_amd import capi
+
+    comm = capi.comm_create(capi.comm_unique_id(), 0, 1)
+    assert capi.comm_neighbours(comm) == (-1, -1)  # a chain of one: no neighbours
+    capi.comm_set_neighbours(comm, 0, 0)
+    assert capi.comm_neighbours(comm) == (0, 0)
+    return comm
+
+
+@pytest.mark.parametrize("elem_sizes", [(4,), (4, 4, 8, 1, 2, 4, 16, 4)], ids=["1plane", "8planes"])
+@pytest.mark.parametrize("g", [16, 64])
+def test_rccl_loopback_exchange_rows(gpu, elem_sizes, g):
+    """ststhip_comm_exchange_rows against itself: g ghost rows of 65536 columns per side, 1 and 8 planes of different
+    element sizes, on a stream of its own behind a kernel that writes the rows to send (stream order)."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    comm = _loopback_comm()
+    W, owned = 65536, 3 * g
+    rows = owned + 2 * g
+    gen = torch.Generator(device="cuda").manual_seed(1000 + g)
+    planes = [torch.randint(0, 256, (rows, W * e), dtype=torch.uint8, device=gpu, generator=gen) for e in elem_sizes]
+    before = [p.clone() for p in planes]
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        for p, b in zip(planes, before):  # the producer of the rows to send runs on the exchange's stream, in front of it
+            p[g:2 * g] += 1
+            b[g:2 * g] += 1
+    row_bytes = [W * e for e in elem_sizes]
+    at = lambda p, r, rb: p.data_ptr() + r * rb  # noqa: E731
+    capi.comm_exchange_rows(comm,
+                            [at(p, g, rb) for p, rb in zip(planes, row_bytes)],              # send_up: first owned rows
+                            [at(p, g + owned - g, rb) for p, rb in zip(planes, row_bytes)],  # send_down: last owned rows
+                            [at(p, 0, rb) for p, rb in zip(planes, row_bytes)],              # recv_up: ghost rows above
+                            [at(p, g + owned, rb) for p, rb in zip(planes, row_bytes)],      # recv_down: ghost rows below
+                            row_bytes, g, stream=s.cuda_stream)
+    s.synchronize()
+    for i, (p, b) in enumerate(zip(planes, before)):
+        assert torch.equal(p[g:g + owned], b[g:g + owned]), f"plane {i}: owned rows changed"
+        assert torch.equal(p[:g], b[owned:owned + g]), f"plane {i}: ghost rows above are not the ring's lower rows"
+        assert torch.equal(p[g + owned:], b[g:2 * g]), f"plane {i}: ghost rows below are not the ring's upper rows"
+    capi.comm_destroy(comm)
+
+
+def _ring_of_one_exchange():
+    """The same wiring as an exchange callback: device-to-device copies in stream order (the reference the RCCL
+    loopback is compared with)."""
+    import ctypes as C
+
+    from stencilstream_amd import capi
+
+    lib = capi.load()
+
+    def exchange(n_planes, send_up, send_down, recv_up, recv_down, row_bytes, n_rows, stream):
+        for p in range(n_planes):
+            n = row_bytes[p] * n_rows
+            capi.check(lib.ststhip_memcpy_d2d(C.c_void_p(recv_down[p]), C.c_void_p(send_up[p]), n, C.c_void_p(stream)), "d2d")
+            capi.check(lib.ststhip_memcpy_d2d(C.c_void_p(recv_up[p]), C.c_void_p(send_down[p]), n, C.c_void_p(stream)), "d2d")
+
+    return exchange
+
+
+@pytest.mark.parametrize("every", ["0", "1", "2"])
+def test_strip_driver_over_rccl_loopback(gpu, oracle, monkeypatch, every):
+    """ststhip_strip_advance with RCCL as the exchange, on one GPU: the middle strip of three whose communicator names
+    itself on both sides.  Its rows then evolve like a grid that is periodic in the rows -- which the oracle computes
+    on three copies of the strip stacked (the middle copy, while the true rim is further away than the generations
+    reach) -- and the same strip driven by device-to-device copies as the exchange callback must agree bit for bit.
+    Jacobi (both kernels, one plane) and HotSpot (two planes); every = STSTHIP_EXCHANGE_EVERY (launches per exchange)."""
+    from stencilstream_amd import capi
+
+    monkeypatch.setenv("STSTHIP_EXCHANGE_EVERY", every)
+    capi.init(0)
+    comm = _loopback_comm()
+    R, W = 1000, 900
+    rng = np.random.default_rng(4242)
+    grid = rng.random((R, W), dtype=np.float32)
+
+    def both(app, params, halo, uploads, n_first, n_second, planes):
+        results = []
+        for kwargs in ({"comm": comm}, {"exchange": _ring_of_one_exchange()}):
+            strip = capi.Strip(app, params, halo, 3 * R, W, 1, 3, **kwargs)
+            assert (strip.row_begin, strip.row_end) == (R, 2 * R)
+            for i, a in enumerate(uploads):
+                strip.upload(i, a)
+            strip.warm_up()
+            strip.advance(0, n_first)
+            strip.advance(n_first, n_second, blocking=True)
+            results.append([strip.download(i, dt) for i, dt in planes])
+            launches, exchanges = strip.counters()
+            assert exchanges >= 3
+            strip.close()
+        for a, b in zip(*results):
+            assert np.array_equal(bits(a), bits(b)), f"{app}: RCCL loopback differs from the copy exchange"
+        return results[0]
+
+    for coef, halo in (([0.2, 0.21, 0.19, 0.22, 0.18], 0.25), ([0.2] * 5, 0.0)):
+        p = capi.JacobiParams()
+        for i, c in enumerate(coef):
+            p.coef[i] = c
+        got = both("jacobi5general", p, np.float32(halo).tobytes(), [grid], 40, 13, [(0, np.float32)])[0]
+        want = oracle.jacobi("Jacobi5General", coef, np.tile(grid, (3, 1)), 53, halo=halo, n_threads=8)[R:2 * R]
+        assert np.array_equal(bits(got), bits(want)), f"jacobi {coef[0]}"
+
+    cells = np.zeros((R, W), dtype=oracle.HOTSPOT_CELL)
+    cells["temp"] = 320 + 10 * rng.random((R, W), dtype=np.float32)
+    cells["power"] = rng.random((R, W), dtype=np.float32) * 0.01
+    hp = oracle.hotspot_params(3 * R, W)
+    got = both("hotspot", capi.HotspotParams(hp.Rx_1, hp.Ry_1, hp.Rz_1, hp.Cap_1), bytes(8),
+               [np.ascontiguousarray(cells["temp"]), np.ascontiguousarray(cells["power"])], 25, 8,
+               [(0, np.float32), (1, np.float32)])
+    want = oracle.hotspot(hp, np.tile(cells, (3, 1)), 33, n_threads=8)[R:2 * R]
+    assert np.array_equal(bits(got[0]), bits(np.ascontiguousarray(want["temp"])))
+    assert np.array_equal(bits(got[1]), bits(np.ascontiguousarray(want["power"])))
+    capi.comm_destroy(comm)
+
+
+def test_strip_driver_over_rccl_loopback_config5_shape(gpu):
+    """The exchange of BASELINE configs[4] at its true message size: one GPU's strip of the 65536^2 grid's width
+    (2048 x 65536 here; 16 generations x 2 launches per group = 32 ghost rows of 256 KiB per side and exchange),
+    100 generations over the RCCL loopback against the copy exchange, bit for bit, with the launch / exchange counts."""
+    import torch
+
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    comm = _loopback_comm()
+    R, W = 2048, 65536
+    p = capi.JacobiParams()
+    for i in range(5):
+        p.coef[i] = 0.2
+    init = torch.rand(R, W, device=gpu, generator=torch.Generator(device="cuda").manual_seed(65536))
+    torch.cuda.synchronize()
+    outs = []
+    for kwargs in ({"comm": comm}, {"exchange": _ring_of_one_exchange()}):
+        strip = capi.Strip("jacobi5general", p, np.float32(0).tobytes(), 3 * R, W, 1, 3, **kwargs)
+        strip.upload_from_device(0, init.data_ptr(), init.numel() * 4)
+        strip.warm_up()
+        strip.advance(0, 100, blocking=True)
+        ptr, row_bytes = strip.plane(0)
+        out = torch.empty_like(init)
+        capi.check(capi.load().ststhip_memcpy_d2d(out.data_ptr(), ptr, R * row_bytes, None), "d2d")
+        capi.check(capi.load().ststhip_stream_synchronize(None), "sync")
+        outs.append(out)
+        launches, exchanges = strip.counters()
+        assert launches >= 7 and exchanges >= 2, (launches, exchanges)
+        strip.close()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert not torch.equal(outs[0], init)
+    capi.comm_destroy(comm)
