@@ -22,16 +22,21 @@ What the JSON line carries besides the contract's fields:
   roofline      the dominant kernel measured live with HIP events on the launch stream (full-grid launches of
                 the deepest compiled blocking depth).  `achieved` / `frac` are SURVEY 8d's ALGORITHMIC bytes
                 (8 B per cell-update x generations per launch) over the launch time -- with temporal blocking
-                this exceeds the 8 TB/s peak by design (each cell moves once per T generations), so the line
-                also carries the physical fractions from the PMC passes of this very command
-                (profiles/r03_bench_counters.json): HBM bytes and VALU wave-instructions per launch, and
-                `timed_path`: the same two sums over the launches of ONE TIMED STEP (interiors and bands of the
-                row strips), so that bytes per step / ms_per_step can be held against 8 TB/s.
+                this exceeds the 8 TB/s peak by design (each cell moves once per T generations) --, `traffic` the
+                HBM bytes of such a launch from the PMC passes.  The PHYSICAL fractions lead with `timed_path`:
+                HBM bytes and VALU wave-instructions of ONE TIMED STEP (all its launches: two row strips side by
+                side, their bands) from the committed PMC passes of this file's own legs
+                (profiles/r04_bench_counters.json, tools/profile_bench_r04.sh) over THIS run's ms_per_step;
+                `full_grid_launch` is the same per launch over kernel_ms.  VALU fractions on both bases (the guide's
+                2 cycles at 2.4 GHz, this repository's measured 1.09 ns); `bound` is derived from the fractions.
   verified      the result of the LAST TIMED step is compared, bit for bit over the whole grid, with the same
                 1000 generations computed by a different code path (general-coefficient kernel, one generation per
                 launch, one row strip), and with the CPU oracle on windows on the rim of the square (see verify()).
-  legs          template_api (the reference's unchanged examples/jacobi binary, its own `Walltime:`), hotspot_8192,
-                fdtd_max_grid, general_coefficients: the other BASELINE configurations and the API path.
+  legs          random_init (the headline path on random data, with the GPU's shader clock sampled during both),
+                general_coefficients / general_coefficients_fma (the kernel any C++ functor compiles to, with
+                -ffp-contract=off and in the reference's own GPU compile mode), hotspot_8192, fdtd_max_grid -- each
+                with its own `roofline` (algorithmic and physical fractions, binding resource) --, template_api /
+                template_api_fma (the reference's unchanged examples/jacobi binary, its own `Walltime:`).
   cpu_baseline  the CPU port timed on this box's host cores, bounded sample.
 """
 import argparse
@@ -55,12 +60,15 @@ HBM_COPY_GUIDE_GBS = 6290.0
 HBM_COPY_MEASURED_GBS = 5400.0
 BYTES_PER_CELL_UPDATE = 8  # 2 * sizeof(float) * n_subiterations (scripts/benchmark-common.jl:150-151)
 COEF = [0.2, 0.2, 0.2, 0.2, 0.2]  # examples/jacobi/scripts/benchmark.jl:44-45
-# VALU issue peak: one wave64 fp32 instruction per 2 cycles and SIMD (MI355X_MICROARCH.md, cycle constants) at the
-# ~2.06 GHz the chip holds under this load = 0.97 ns; measured with every SIMD busy: 0.97-1.09 ns
-# (tools/microbench/valu_rate.hip, profiles/r01_microbench_valu_rate.txt).  The fractions use the measured 1.09.
-VALU_NS_PER_WAVE_INSTRUCTION = 1.09
+# VALU issue peak, two bases, both reported: (a) the guide's: one wave64 fp32 instruction per 2 cycles and SIMD
+# (MI355X_MICROARCH.md, cycle constants: v_fma_f32 wave64 = 2 cycles on SIMD-32) at the 2.4 GHz peak clock = 0.833 ns;
+# (b) this repository's own measurement with every SIMD busy, at the clock the chip holds under such a load:
+# 1.09 ns (tools/microbench/valu_rate.hip, profiles/r01_microbench_valu_rate.txt).  `bound` is derived on basis (b),
+# the one this chip has been seen to reach.
+VALU_NS_GUIDE = 2.0 / 2.4
+VALU_NS_MEASURED = 1.09
 N_SIMDS = 1024
-COUNTER_FILE = os.path.join(ROOT, "profiles", "r03_bench_counters.json")
+COUNTER_FILE = os.path.join(ROOT, "profiles", "r04_bench_counters.json")
 EXAMPLES = os.path.join(ROOT, "build", "examples")
 
 
@@ -83,6 +91,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the template_api / hotspot / fdtd legs")
+    ap.add_argument("--profile-legs", action="store_true",
+                    help="run every kernel leg three times and nothing else (the program tools/profile_bench_r04.sh "
+                         "profiles); prints the sequence of legs instead of the bench line")
     ap.add_argument("--debug-host-exchange", action="store_true",
                     help="debugging: all ranks on cuda:0, gloo process group, ghost rows through host memory")
     ap.add_argument("--strip-domain", action="store_true",
@@ -142,6 +153,7 @@ def cpu_baseline(size, generations):
     (OpenMP) running the reference's unchanged examples/jacobi source; else the oracle."""
     cores = usable_cores()
     binary = os.path.join(EXAMPLES, "jacobi_Jacobi5General_cpu")
+    fallback_reason = None
     if os.path.exists(binary):
         env = dict(os.environ, OMP_NUM_THREADS=str(cores))
         its = max(8, generations * 3)  # ~10-20 s of CPU work on 16 cores (3-3.5 Gcell-updates/s)
@@ -159,8 +171,10 @@ def cpu_baseline(size, generations):
                                   "Walltime.  The reference's own cpu backend needs a SYCL compiler (icpx), absent here",
                 "sample": f"Jacobi5General {size}x{size}, {its} generations, {dt:.1f} s",
             }
-        except Exception:  # noqa: BLE001 -- fall through to the oracle
-            pass
+        except Exception as e:  # noqa: BLE001 -- fall through to the oracle, and say why
+            fallback_reason = f"{os.path.basename(binary)} failed: {str(e)[:200]}"
+    else:
+        fallback_reason = f"build/examples/{os.path.basename(binary)} not built (needs /root/reference at build time)"
     from oracle import oracle as O
 
     grid = O.jacobi_init(size, size)
@@ -177,6 +191,7 @@ def cpu_baseline(size, generations):
                           "(cpu/StencilUpdate.hpp:109-142,185-223), transition function through a pointer, rows "
                           "shared among threads with OpenMP",
         "sample": f"Jacobi5General {size}x{size}, {generations} generations, {dt:.1f} s",
+        "fallback_reason": fallback_reason,
     }
 
 
@@ -258,43 +273,129 @@ def load_counters():
         return None
 
 
-def attach_counters(roofline, kernel_key, kernel_ms, ms_per_step, launches_per_step):
-    """HBM bytes and VALU instructions per launch (dominant kernel) and per timed step from the committed PMC
-    passes of this command (tools/profile_bench_r03.sh -> profiles/r03_bench_counters.json)."""
-    roofline["traffic"] = None
-    roofline["fractions"] = {"algorithmic_hbm": roofline["frac"], "physical_hbm": None, "valu_issue": None}
-    roofline["timed_path"] = None
-    data = load_counters()
-    counters = (data or {}).get("kernels", {}).get(kernel_key)
-    if not counters:
-        roofline["counters"] = f"no PMC profile of {kernel_key} in {os.path.relpath(COUNTER_FILE, ROOT)}"
-        return
-    traffic = counters["hbm_bytes_per_launch"]
-    roofline["traffic"] = traffic
-    f = roofline["fractions"]
-    f["physical_hbm"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-    f["physical_hbm_of_copy_rate_guide_6.29TBps"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_COPY_GUIDE_GBS
-    f["physical_hbm_of_copy_rate_measured_5.4TBps"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_COPY_MEASURED_GBS
-    valu = counters.get("valu_wave_instructions_per_launch")
+def physical_fractions(hbm_bytes, valu, seconds):
+    """Fractions of the two physical roofs for work that moved `hbm_bytes` through HBM and issued `valu` VALU
+    wave-instructions in `seconds`: HBM against the 8 TB/s of the specification (and against the two copy rates),
+    VALU issue on both bases (VALU_NS_GUIDE, VALU_NS_MEASURED).  `bound` = the larger of the two fractions, VALU on
+    the measured basis; `binding` says how close that roof is."""
+    gbps = hbm_bytes / seconds / 1e9
+    out = {"hbm_GBps": gbps, "physical_hbm": gbps / HBM_PEAK_GBS,
+           "physical_hbm_of_copy_rate_guide_6.29TBps": gbps / HBM_COPY_GUIDE_GBS,
+           "physical_hbm_of_copy_rate_measured_5.4TBps": gbps / HBM_COPY_MEASURED_GBS,
+           "valu_issue": None, "bound": "hbm"}
     if valu:
-        f["valu_issue"] = valu * VALU_NS_PER_WAVE_INSTRUCTION * 1e-6 / N_SIMDS / kernel_ms
-        roofline["valu_wave_instructions_per_launch"] = valu
-        roofline["bound"] = "valu" if f["valu_issue"] >= f["physical_hbm"] else "hbm"
-    roofline["counters"] = counters.get("source")
-    step = (data or {}).get("timed_step", {}).get(kernel_key)
-    if step and step.get("launches_per_step") == launches_per_step:
-        hbm, valu_step = step["hbm_bytes_per_step"], step.get("valu_wave_instructions_per_step")
-        roofline["timed_path"] = {
-            "launches_per_step": launches_per_step,
-            "launch_shapes": step.get("launch_shapes"),
-            "hbm_bytes_per_step": hbm,
-            "valu_per_step": valu_step,
-            "physical_hbm_frac": hbm / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "valu_frac": (valu_step * VALU_NS_PER_WAVE_INSTRUCTION * 1e-6 / N_SIMDS / ms_per_step) if valu_step else None,
-            "sum_kernel_ms_per_step": step.get("sum_kernel_ms_per_step"),
-            "note": "sums over the launches of one timed step (interiors and bands of the row strips, from the same "
-                    "PMC passes) over THIS run's ms_per_step",
-        }
+        guide = valu * VALU_NS_GUIDE * 1e-9 / N_SIMDS / seconds
+        measured = valu * VALU_NS_MEASURED * 1e-9 / N_SIMDS / seconds
+        out["valu_issue"] = {"guide_2_cycles_at_2.4GHz": guide, "measured_1.09ns": measured}
+        out["bound"] = "valu" if measured >= out["physical_hbm_of_copy_rate_guide_6.29TBps"] else "hbm"
+        out["bound_rule"] = ("the larger of valu_issue.measured_1.09ns and physical_hbm_of_copy_rate_guide_6.29TBps: "
+                             "each roof at the rate this chip has been seen to reach")
+    return out
+
+
+def leg_counters(name, launches_per_call):
+    """PMC sums of one call of leg `name` from the committed profile of this file's own `--profile-legs` run
+    (tools/profile_bench_r04.sh -> profiles/r04_bench_counters.json), or (None, why).  Attached only when the call
+    made the same number of launches as the profiled one: another launch plan moves other bytes."""
+    data = load_counters()
+    if not data:
+        return None, f"{os.path.relpath(COUNTER_FILE, ROOT)} is missing"
+    leg = (data.get("legs") or {}).get(name)
+    if not leg:
+        return None, f"no leg {name} in {os.path.relpath(COUNTER_FILE, ROOT)}"
+    if launches_per_call is not None and int(leg.get("launches_per_call", -1)) != int(launches_per_call):
+        return None, (f"the profiled call made {leg.get('launches_per_call')} launches, this one {launches_per_call}: "
+                      "another launch plan, counters not attached")
+    return leg, None
+
+
+def leg_roofline(name, launches_per_call, seconds_per_call, algorithmic_frac):
+    """`roofline` of a leg: SURVEY 8(d)'s algorithmic fraction beside the physical ones of the same call."""
+    roof = {"algorithmic_hbm": algorithmic_frac, "traffic": None}
+    leg, why = leg_counters(name, launches_per_call)
+    if not leg:
+        roof["counters"] = why
+        return roof
+    roof["traffic"] = leg["hbm_bytes_per_call"]
+    roof["traffic_unit"] = "HBM bytes per call of the leg (all its launches), PMC"
+    roof["valu_wave_instructions"] = leg.get("valu_per_call")
+    roof.update(physical_fractions(leg["hbm_bytes_per_call"], leg.get("valu_per_call"), seconds_per_call))
+    if leg.get("sq"):
+        roof["wave_cycles"] = leg["sq"]
+    roof["kernel_shapes"] = [{k: sh.get(k) for k in ("kernel", "grid_size", "launches_per_call", "avg_us", "vgprs",
+                                                     "lds_bytes", "scratch_bytes")} for sh in leg.get("shapes", [])[:4]]
+    roof["counters"] = leg.get("source")
+    return roof
+
+
+class ClockSampler:
+    """Average shader clock of the GPU while a leg runs, sampled in-process from the driver's sysfs files (a thread
+    that reads a file every 20 ms; no subprocess, nothing on the GPU).  None where the box does not expose them."""
+
+    def __init__(self, device_index=0):
+        import glob
+
+        self.files = []
+        cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or
+                 glob.glob(os.path.join(c, "hwmon", "hwmon*", "freq1_input"))]
+        if device_index < len(cards):
+            card = cards[device_index]
+            self.files = glob.glob(os.path.join(card, "hwmon", "hwmon*", "freq1_input")) or \
+                [os.path.join(card, "pp_dpm_sclk")]
+        self.samples = []
+        self._stop = None
+        self._thread = None
+
+    def _read(self):
+        for f in self.files:
+            try:
+                text = open(f).read()
+            except OSError:
+                continue
+            if f.endswith("freq1_input"):
+                return int(text) / 1e6  # Hz -> MHz
+            for line in text.splitlines():
+                if line.rstrip().endswith("*"):
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
+                    if m:
+                        return float(m.group(1))
+        return None
+
+    def __enter__(self):
+        import threading
+
+        self.samples = []
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                v = self._read()
+                if v:
+                    self.samples.append(v)
+                self._stop.wait(0.02)
+
+        if self.files:
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread:
+            self._thread.join()
+
+    def report(self):
+        if not self.samples:
+            return None
+        label = None
+        if self.files and self.files[0].endswith("freq1_input"):
+            try:
+                label = open(self.files[0].replace("_input", "_label")).read().strip()
+            except OSError:
+                pass
+        return {"mean_MHz": sum(self.samples) / len(self.samples), "min_MHz": min(self.samples),
+                "max_MHz": max(self.samples), "samples": len(self.samples), "source": self.files[0], "label": label}
 
 
 def hotspot_params(capi, n):
@@ -313,42 +414,49 @@ def hotspot_params(capi, n):
     return capi.HotspotParams(float(f32(1) / rx), float(f32(1) / ry), float(f32(1) / rz), float(step / cap))
 
 
-def best_rate(fn, cells, reps=3):
-    fn()
+def best_time(fn, reps=3):
+    """(best seconds, what the last call returned) of `reps` calls after one warm-up call"""
+    last = fn()
     best = 1e9
     for _ in range(reps):
         t0 = time.perf_counter()
-        fn()
+        last = fn()
         best = min(best, time.perf_counter() - t0)
-    return cells / best / 1e9, best
+    return best, last
 
 
-def extra_legs(torch, capi, device, stream, gens):
-    """The other BASELINE configurations and the API path, each with its grid resident in HBM unless it says
-    otherwise; none of them is `value`."""
+def kernel_legs(torch, capi, device, stream, gens, size=16384):
+    """The legs that are sweeps on a grid resident in HBM, through the C ABI: name -> setup() -> dict(call, cells,
+    bytes_per_cell_update, what).  `call()` runs ONE blocking ststhip_app_run and returns its run info.  Shared by the
+    default run (timed, min of 3) and by `--profile-legs` (1 + 2 calls each under rocprofv3)."""
     import numpy as np
 
-    legs = {}
-    # configs[1] through the template API: the reference's unchanged examples/jacobi/jacobi.cpp, compiled against
-    # this backend; the application's own `Walltime:` (allocation of the swap grids, upload, sweeps --
-    # cuda/StencilUpdate.hpp:123-144), min of 3 after one warm-up run as examples/jacobi/scripts/benchmark.jl:43-94
-    binary = os.path.join(EXAMPLES, "jacobi_Jacobi5General_hip")
-    if os.path.exists(binary):
-        try:
-            cmd = [binary, "16384", "16384", str(gens), "/dev/null"] + [str(c) for c in COEF]
-            walltime_of(cmd)
-            dt = min(walltime_of(cmd) for _ in range(3))
-            legs["template_api"] = {
-                "value": 16384 * 16384 * gens / dt / 1e9, "unit": "Gcell-updates/s", "walltime_s": dt,
-                "what": f"build/examples/jacobi_Jacobi5General_hip 16384 16384 {gens} /dev/null 0.2 x5: the reference's "
-                        "unchanged source on stencil::hip (a C++ functor is opaque: the 9-flop general kernel); the "
-                        "application's own Walltime, which includes the upload of the 1 GiB grid; min of 3 after a warm-up"}
-        except Exception as e:  # noqa: BLE001
-            legs["template_api"] = {"value": None, "why": str(e)[:200]}
-    else:
-        legs["template_api"] = {"value": None, "why": "build/examples/jacobi_Jacobi5General_hip not built (needs /root/reference at build time)"}
-    # configs[2]: HotSpot fp32 8192^2 on per-field planes (the reference is fp32, SURVEY section 0)
-    try:
+    halo0 = np.float32(0.0).tobytes()
+
+    def jacobi(app, coef, init, n=gens, env=None, H=size, W=size):
+        def setup():
+            p = capi.JacobiParams()
+            for i, c in enumerate(coef):
+                p.coef[i] = c
+            src = init(H, W)
+            dst = torch.empty_like(src)
+            dom = capi.Domain(H, W, 0, H, W)
+            torch.cuda.synchronize()
+
+            def call():
+                with with_env(env or {}):
+                    return capi.app_run(app, p, halo0, dom, [src.data_ptr()], [dst.data_ptr()], 0, n, blocking=True,
+                                        stream=stream.cuda_stream)
+            return {"call": call, "cells": H * W * n, "keep": (src, dst, p), "src": src, "dst": dst, "params": p,
+                    "dom": dom, "generations": n, "app": app, "shape": (H, W)}
+        return setup
+
+    square = lambda H, W: init_grid_device(torch, H, W, 0, H, device)  # noqa: E731
+    random = lambda H, W: torch.rand(H, W, device=device,  # noqa: E731
+                                     generator=torch.Generator(device=device).manual_seed(0x5EED))
+    distinct = [0.2, 0.21, 0.19, 0.22, 0.18]
+
+    def hotspot():
         H = W = 8192
         temp = torch.full((H, W), 30.0, device=device)
         power = torch.zeros(H, W, device=device)
@@ -358,18 +466,13 @@ def extra_legs(torch, capi, device, stream, gens):
         hp = hotspot_params(capi, H)
         torch.cuda.synchronize()
         n = 1000
-        rate, dt = best_rate(lambda: capi.app_run("hotspot", hp, np.zeros(2, np.float32).tobytes(), dom,
-                                                  [temp.data_ptr(), power.data_ptr()], [t.data_ptr() for t in out],
-                                                  0, n, blocking=True, stream=stream.cuda_stream), H * W * n)
-        legs["hotspot_8192"] = {"value": rate, "unit": "Gcell-updates/s", "generations": n, "s": dt,
-                                "frac_of_hbm_roofline": rate * 16 / HBM_PEAK_GBS,
-                                "what": "HotSpot 2 x fp32, 8192^2, per-field planes, 1000 generations, resident grid "
-                                        "(BASELINE configs[2]); roofline 16 B per cell-update at 8 TB/s"}
-        del temp, power, out
-    except Exception as e:  # noqa: BLE001
-        legs["hotspot_8192"] = {"value": None, "why": str(e)[:200]}
-    # configs[3]: FDTD coefficient resolver on the 4608^2 grid of max_grid.json, kernel rate
-    try:
+
+        def call():
+            return capi.app_run("hotspot", hp, np.zeros(2, np.float32).tobytes(), dom, [temp.data_ptr(), power.data_ptr()],
+                                [t.data_ptr() for t in out], 0, n, blocking=True, stream=stream.cuda_stream)
+        return {"call": call, "cells": H * W * n, "keep": (temp, power, out, hp), "generations": n}
+
+    def fdtd():
         H = W = 4608
         p = capi.FdtdParams(dt=8.1e-19, t_0=3e-13, tau=1e-13, omega=7.5e14, cutoff_iteration=10 ** 9,
                             detect_iteration=0, source_radius_squared=100.0, source_r=H / 2, source_c=W / 2,
@@ -382,19 +485,115 @@ def extra_legs(torch, capi, device, stream, gens):
         dom = capi.Domain(H, W, 0, H, W)
         torch.cuda.synchronize()
         n = 1200
-        rate, dt = best_rate(lambda: capi.app_run("fdtd_coef_grouped", p, np.zeros(8, np.float32).tobytes(), dom,
-                                                  [t.data_ptr() for t in pa], [t.data_ptr() for t in pb], 0, n,
-                                                  blocking=True, stream=stream.cuda_stream), H * W * n)
-        legs["fdtd_max_grid"] = {"value": rate, "unit": "Gcell-updates/s", "generations": n, "s": dt,
-                                 "frac_of_hbm_roofline": rate * 128 / HBM_PEAK_GBS,
-                                 "what": "FDTD coef resolver, 4608^2 (max_grid.json's grid), 2 sub-iterations, the cell as "
-                                         "two planes of 16-byte halves, kernel rate on a resident grid (BASELINE "
-                                         "configs[3]); roofline 128 B per cell-update at 8 TB/s"}
-        del pa, pb, material
+
+        def call():
+            return capi.app_run("fdtd_coef_grouped", p, np.zeros(8, np.float32).tobytes(), dom, [t.data_ptr() for t in pa],
+                                [t.data_ptr() for t in pb], 0, n, blocking=True, stream=stream.cuda_stream)
+        return {"call": call, "cells": H * W * n, "keep": (pa, pb, material, p), "generations": n}
+
+    T = int(capi.app_info("jacobi5uniform").max_generations)
+    return {
+        # `value`'s own path, and the same kernel as full-grid launches (one row strip, launches of the full depth only:
+        # what roofline.kernel_ms times)
+        "headline": {"setup": jacobi("jacobi5general", COEF, square), "bytes": 8,
+                     "what": f"Jacobi5General {size}^2, coefficients 5 x 0.2, halo 0, centred-square input: the uniform-"
+                             "coefficient form, two row strips with their bands (the path `value` times)"},
+        "headline_full_grid": {"setup": jacobi("jacobi5general", COEF, square, n=15 * T, env={"STSTHIP_VIRTUAL_STRIPS": "1"}),
+                               "bytes": 8, "what": "the same kernel as full-grid launches of the full depth on one stream"},
+        "random_init": {"setup": jacobi("jacobi5general", COEF, random), "bytes": 8,
+                        "what": f"the headline path on uniform random input in [0, 1) (torch.rand, seed 0x5EED; SURVEY 8(d) "
+                                "config 2's random variant): every lane adds different numbers"},
+        "general_coefficients": {"setup": jacobi("jacobi5general", distinct, square), "bytes": 8,
+                                 "what": "Jacobi5General kernel with coefficients 0.2 0.21 0.19 0.22 0.18 (nine flops per "
+                                         "cell: what any C++ functor compiles to) through the C ABI, resident grid"},
+        "general_coefficients_fma": {"setup": jacobi("jacobi5general_fma", distinct, square), "bytes": 8,
+                                     "what": "the same function compiled with -ffp-contract=fast, the reference's own GPU "
+                                             "compile mode (five fused operations per cell; results within the stated fp32 "
+                                             "tolerance, tests/test_parity_gpu.py), kernel rate on a resident grid"},
+        "hotspot_8192": {"setup": hotspot, "bytes": 16,
+                         "what": "HotSpot 2 x fp32, 8192^2, per-field planes, 1000 generations, resident grid (BASELINE "
+                                 "configs[2]); roofline 16 B per cell-update at 8 TB/s"},
+        "fdtd_max_grid": {"setup": fdtd, "bytes": 128,
+                          "what": "FDTD coef resolver, 4608^2 (max_grid.json's grid), 2 sub-iterations, the cell as two planes "
+                                  "of 16-byte halves, kernel rate on a resident grid (BASELINE configs[3]); roofline 128 B per "
+                                  "cell-update at 8 TB/s"},
+    }
+
+
+def run_kernel_leg(torch, name, leg, reps=3, clock=False):
+    """Time one leg (min of `reps` calls after a warm-up) and attach its roofline."""
+    state = leg["setup"]()
+    sampler = ClockSampler() if clock else None
+    if sampler:
+        with sampler:
+            dt, info = best_time(state["call"], reps)
+    else:
+        dt, info = best_time(state["call"], reps)
+    rate = state["cells"] / dt / 1e9
+    out = {"value": rate, "unit": "Gcell-updates/s", "generations": state["generations"], "s": dt,
+           "launches_per_call": int(info.n_launches), "what": leg["what"],
+           "frac_of_hbm_roofline": rate * leg["bytes"] / HBM_PEAK_GBS,
+           "roofline": leg_roofline(name, int(info.n_launches), dt, rate * leg["bytes"] / HBM_PEAK_GBS)}
+    if sampler:
+        out["sclk"] = sampler.report()
+    if "app" in state:
+        from stencilstream_amd import capi
+
+        depth = capi.app_tuned_depth(state["app"], *state["shape"])
+        if depth:
+            out["blocking_depth_by_measurement"] = depth  # the pass driver timed the family's two depths (ststhip.h)
+    return out, state
+
+
+def example_leg(binary_name, args, what, cells):
+    """An unchanged example binary by its own `Walltime:` (min of 3 after one warm-up run, as
+    examples/jacobi/scripts/benchmark.jl:43-94)."""
+    binary = os.path.join(EXAMPLES, binary_name)
+    if not os.path.exists(binary):
+        return {"value": None, "why": f"build/examples/{binary_name} not built (needs /root/reference at build time)"}
+    try:
+        cmd = [binary] + args
+        walltime_of(cmd)
+        dt = min(walltime_of(cmd) for _ in range(3))
+        return {"value": cells / dt / 1e9, "unit": "Gcell-updates/s", "walltime_s": dt, "what": what}
     except Exception as e:  # noqa: BLE001
-        legs["fdtd_max_grid"] = {"value": None, "why": str(e)[:200]}
-    torch.cuda.empty_cache()
-    return legs
+        return {"value": None, "why": str(e)[:200]}
+
+
+FIRST_USE_NOTE = ("outside Walltime (as the reference excludes queue creation, cuda/StencilUpdate.hpp:124-128): creation "
+                  "of the runtime's stream set and the copy engines' first use (a 1 MiB copy each way), which happen "
+                  "when the host first asks the runtime for pinned memory, i.e. when the example allocates its grid")
+
+
+def profile_legs(torch, capi, device, stream, gens):
+    """`--profile-legs`: every kernel leg once as warm-up and twice more, one after the other, nothing else -- the
+    program tools/profile_bench_r04.sh runs under rocprofv3 (--kernel-trace, then one --pmc pass per counter group).
+    Prints the sequence (leg, calls, launches per call) so that the summariser can cut the dispatch-ordered list of
+    sweep launches into legs without looking at kernel names."""
+    sequence = []
+    # depths the unprofiled run chose for the families whose depth is measured ("leg=depth,..."): the counter passes
+    # must plan the same launches, whatever the counters do to the timing of the probes
+    pinned = dict(item.split("=") for item in os.environ.get("STSTHIP_BENCH_LEG_DEPTHS", "").split(",") if "=" in item)
+    for name, leg in kernel_legs(torch, capi, device, stream, gens).items():
+        if name == "random_init":
+            continue  # the headline's kernels on other data: same launches, same counters
+        state = leg["setup"]()
+        launches, seconds = [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            with with_env({"STSTHIP_TUNE_DEPTH": pinned[name]} if name in pinned else {}):
+                info = state["call"]()
+            seconds.append(time.perf_counter() - t0)
+            launches.append(int(info.n_launches))
+        # (a family whose depth is measured probes on its first call: that call makes other launches than the later ones;
+        # the summariser averages over the calls that made as many launches as the last one)
+        depth = capi.app_tuned_depth(state["app"], *state["shape"]) if "app" in state else 0
+        sequence.append({"leg": name, "launches": launches, "launches_per_call": launches[-1], "cells_per_call": state["cells"],
+                         "s_per_call_min": min(seconds), "bytes_per_cell_update": leg["bytes"],
+                         "depth_by_measurement": depth or (int(pinned[name]) if name in pinned else None)})
+        del state
+        torch.cuda.empty_cache()
+    print(json.dumps({"profile_legs": sequence}), flush=True)
 
 
 def main():
@@ -422,6 +621,9 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     capi.init(local_rank)
     stream = torch.cuda.Stream(device)  # the stream every sweep is launched on (and timed on)
+    if args.profile_legs:
+        profile_legs(torch, capi, device, stream, args.generations)
+        return
 
     W, gens = (65536 if args.config5 else args.size), args.generations
     if args.rows_per_gpu:
@@ -669,47 +871,102 @@ def main():
             T = gens_timed / max(prof.n_launches, 1)
             alg_bytes = total_rows * W * BYTES_PER_CELL_UPDATE * T
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-            kernel_key = f"{form}:{total_rows}x{W}:T{int(T)}"
-            out["roofline"] = {
-                "bound": "valu",
+            default_size = (total_rows, W) == (16384, 16384) and gens == 1000
+            # physical fractions, from the committed PMC passes of this file's own legs (profiles/r04_bench_counters.json)
+            # over THIS run's times.  The lead is the timed path -- what `value` is --, the full-grid launch the footnote.
+            timed, why_t = leg_counters("headline", launches_per_step) if default_size else (None, "not the profiled grid")
+            full, why_f = leg_counters("headline_full_grid", None) if default_size else (None, "not the profiled grid")
+            roof = {
+                "bound": "valu",  # replaced below by the fractions' verdict when the counters are there
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
                 "kernel": f"sweep_kernel<Sweep<{form}, T={int(info.max_generations)}, "
                           f"K={int(info.cells_per_lane)}, P={int(info.prefetch_rows)}, stages={int(info.stages)}>>",
-                "kernel_key": kernel_key,
                 "kernel_ms": kernel_ms,
                 "launches_timed": int(prof.n_launches),
                 "generations_per_launch": T,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "attainable_copy_rate_GBps": {"guide_float4_copy": HBM_COPY_GUIDE_GBS,
                                               "this_repo_copy_microbenchmark": HBM_COPY_MEASURED_GBS},
-                "note": "achieved/frac: SURVEY 8d algorithmic bytes (8 B x cell-updates) over the launch time; it "
-                        "exceeds 1 because one launch advances T generations while a cell moves through HBM once "
-                        "(temporal blocking).  fractions.physical_hbm = PMC bytes / launch time / 8 TB/s; "
-                        "fractions.valu_issue = VALU wave-instructions x 1.09 ns / 1024 SIMDs / launch time.  "
-                        "kernel_ms is a full-grid launch; the timed steps run two row strips side by side with their "
-                        "boundary bands on streams of their own: timed_path has their sums",
+                "valu_ns_per_wave_instruction": {"guide_2_cycles_at_2.4GHz": VALU_NS_GUIDE, "measured": VALU_NS_MEASURED},
+                "note": "achieved / frac: SURVEY 8(d)'s algorithmic bytes (8 B x cell-updates of one launch) over the live "
+                        "launch time of a FULL-GRID launch (kernel_ms, HIP events); above 1 because a launch advances T "
+                        "generations while a cell crosses HBM once (temporal blocking).  The physical fractions: "
+                        "`timed_path` = HBM bytes and VALU wave-instructions of ONE TIMED STEP (all its launches: two row "
+                        "strips side by side, their bands on streams of their own; PMC) over this run's ms_per_step -- what "
+                        "`value` is; `full_grid_launch` = the same counters per full-grid launch over kernel_ms.  `bound` is "
+                        "the timed path's.",
             }
-            attach_counters(out["roofline"], kernel_key, kernel_ms, ms_per_step, launches_per_step)
+            if timed:
+                roof["timed_path"] = {"launches_per_step": launches_per_step, "hbm_bytes_per_step": timed["hbm_bytes_per_call"],
+                                      "valu_per_step": timed.get("valu_per_call"),
+                                      "sum_kernel_ms_per_step": timed.get("sum_kernel_ms_per_call"),
+                                      **physical_fractions(timed["hbm_bytes_per_call"], timed.get("valu_per_call"),
+                                                           ms_per_step * 1e-3),
+                                      "wave_cycles": timed.get("sq"), "launch_shapes": timed.get("shapes"),
+                                      "counters": timed.get("source")}
+                roof["bound"] = roof["timed_path"]["bound"]
+            else:
+                roof["timed_path"] = {"counters": why_t}
+            if full:
+                n = max(int(full["launches_per_call"]), 1)
+                roof["traffic"] = full["hbm_bytes_per_call"] / n
+                roof["full_grid_launch"] = {"hbm_bytes_per_launch": full["hbm_bytes_per_call"] / n,
+                                            "valu_per_launch": (full.get("valu_per_call") or 0) / n or None,
+                                            **physical_fractions(full["hbm_bytes_per_call"] / n,
+                                                                 (full.get("valu_per_call") or 0) / n or None,
+                                                                 kernel_ms * 1e-3),
+                                            "wave_cycles": full.get("sq"), "profiled_avg_us": full.get("avg_us_per_launch"),
+                                            "counters": full.get("source")}
+            else:
+                roof["full_grid_launch"] = {"counters": why_f}
+            out["roofline"] = roof
             extras = os.environ.get("STSTHIP_BENCH_MINIMAL", "0") == "0"  # profiling runs skip the extra legs
             if extras and not args.no_legs:
-                legs = {}
-                if uniform:
-                    # the general-coefficient kernel (nine flops per cell), same grid, coefficients that differ
-                    q = capi.JacobiParams()
-                    for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
-                        q.coef[i] = c
-                    rate, _ = best_rate(lambda: capi.app_run(app, q, halo, dom, [src.data_ptr()], [dst.data_ptr()], 0,
-                                                             gens, blocking=True, stream=stream.cuda_stream),
-                                        total_rows * W * gens, reps=2)
-                    legs["general_coefficients"] = {"value": rate, "unit": "Gcell-updates/s",
-                                                    "what": "Jacobi5General kernel with coefficients 0.2 0.21 0.19 0.22 "
-                                                            "0.18 through the C ABI, resident grid"}
                 del src, dst
                 torch.cuda.empty_cache()
-                legs.update(extra_legs(torch, capi, device, stream, gens))
+                legs = {}
+                catalogue = kernel_legs(torch, capi, device, stream, gens, size=W)
+                for name in ("random_init", "general_coefficients", "general_coefficients_fma", "hotspot_8192",
+                             "fdtd_max_grid"):
+                    if name.startswith("general") and not uniform:
+                        continue
+                    try:
+                        legs[name], state = run_kernel_leg(torch, name, catalogue[name], reps=2 if "general" in name else 3,
+                                                           clock=(name == "random_init"))
+                        if name == "random_init":
+                            # the headline again on the same box and clock sampler, so that the two are comparable
+                            head, hstate = run_kernel_leg(torch, "headline", catalogue["headline"], reps=3, clock=True)
+                            legs[name]["centred_square_same_protocol"] = {k: head[k] for k in ("value", "s", "sclk")}
+                            del hstate
+                            if not args.no_verify:
+                                ok, report = verify_timed(torch, capi, state["params"], halo, state["dom"], state["src"],
+                                                          state["dst"], gens, stream, total_rows, W, windows=False)
+                                legs[name]["verified"] = bool(ok)
+                                legs[name]["verification"] = report
+                        del state
+                    except Exception as e:  # noqa: BLE001
+                        legs[name] = {"value": None, "why": f"{type(e).__name__}: {str(e)[:200]}"}
+                    torch.cuda.empty_cache()
+                # configs[1] through the template API: the reference's unchanged examples/jacobi/jacobi.cpp compiled against
+                # this backend (a C++ functor is opaque: the nine-flop general kernel); the application's own `Walltime:`
+                # (allocation of the swap grids, upload of the 1 GiB grid over PCIe, sweeps -- cuda/StencilUpdate.hpp:123-144)
+                args_j = ["16384", "16384", str(gens), "/dev/null"] + [str(c) for c in COEF]
+                legs["template_api"] = example_leg(
+                    "jacobi_Jacobi5General_hip", args_j,
+                    f"build/examples/jacobi_Jacobi5General_hip 16384 16384 {gens} /dev/null 0.2 x5: the reference's unchanged "
+                    "source on stencil::hip, bit-identical to the cpu backend (-ffp-contract=off); the application's own "
+                    "Walltime, which includes the upload of the 1 GiB grid; min of 3 after a warm-up; " + FIRST_USE_NOTE,
+                    16384 * 16384 * gens)
+                legs["template_api_fma"] = example_leg(
+                    "jacobi_Jacobi5General_hip_fma", args_j,
+                    "the same unchanged source compiled as the reference compiles its GPU builds (no -ffp-contract flag in "
+                    "its CMakeLists.txt:46-51: multiply-adds fused, five operations per cell; results within abs 1e-5 of "
+                    "the cpu backend after 1000 generations, tests/test_examples.py); its own Walltime, upload included; "
+                    "min of 3 after a warm-up; " + FIRST_USE_NOTE, 16384 * 16384 * gens)
                 out["legs"] = legs
             if not args.no_cpu_baseline and extras:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_generations)

@@ -281,7 +281,16 @@ template <typename F, bool SOA> struct SweepTuning {
     // while a deeper launch saves the same bytes -- the measured optimum is shallow (dense 5 x 5 Jacobi, 16384^2:
     // T = 8: 540, 4: 650, 2: 760 Gcell/s, profiles/r02_tune_radius.txt): the window is capped at 32 words there.
     static constexpr int window_limit = R >= 2 ? 32 : 128;
+    // One-word cells of radius 1 without sub-iterations (the Jacobi family, the Game of Life): sixteen generations on
+    // four stages of four levels are COMPILED as well, because what such a function costs per cell decides between 8
+    // and 16 and the rule cannot see it -- the reference's five-point Jacobi source is nine operations per cell with
+    // -ffp-contract=off (fastest at 8) and five with fused multiply-adds (fastest at 16, like the library's
+    // uniform-coefficient form).  The pass driver measures (ststhip_sweep_desc::alt_generations); unmeasured launches
+    // run `default_generations` = 8, round 3's depth.
+    static constexpr bool thin_deep = (W == 1 && NS == 1 && R == 1);
     static constexpr int pick_t(int k) {
+        if (thin_deep && nominal_window(16, k) <= window_limit && geometry_ok(16, k))
+            return 16;
         // two-word cells with one sub-iteration (HotSpot): twelve generations on four stages of three levels
         if (W == 2 && NS == 1 && R == 1 && nominal_window(12, k) <= window_limit && geometry_ok(12, k))
             return 12;
@@ -344,6 +353,8 @@ template <typename F, bool SOA> struct SweepTuning {
     static constexpr bool interior_variant = (W * NS <= 16);
     static constexpr int min_waves_per_simd = 1;
     static constexpr int stages = pick_shape(cells_per_lane).w;
+    // the depth unmeasured launches run with (0: max_generations); see thin_deep above
+    static constexpr int default_generations = (max_generations == 16 && thin_deep) ? 8 : 0;
 };
 
 namespace internal {
@@ -398,6 +409,17 @@ template <typename F, bool SOA> constexpr bool taper_beside_for() {
         return true;
 }
 
+// SweepTuning<F, SOA>::default_generations (optional member, default 0 = max_generations): the blocking depth of
+// launches nobody has measured; a value below max_generations makes the pass driver time both on the first long call
+// for a grid shape and keep the faster (ststhip_sweep_desc::alt_generations).
+template <typename F, bool SOA> constexpr int default_generations_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::default_generations; })
+        return SweepTuning<F, SOA>::default_generations > 0 ? SweepTuning<F, SOA>::default_generations
+                                                             : SweepTuning<F, SOA>::max_generations;
+    else
+        return SweepTuning<F, SOA>::max_generations;
+}
+
 template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
     if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })
         return SweepTuning<F, SOA>::trapezoid_fill;
@@ -426,6 +448,7 @@ template <typename F, bool SOA> struct SweepTuning<internal::NarrowForm<F>, SOA>
     static constexpr bool interior_variant = SweepTuning<F, SOA>::interior_variant;
     static constexpr int min_waves_per_simd = SweepTuning<F, SOA>::min_waves_per_simd;
     static constexpr int stages = internal::stages_for<F, SOA>();
+    static constexpr int default_generations = internal::default_generations_for<F, SOA>();
     static constexpr bool narrow_form = false;
     static constexpr bool trapezoid_fill = internal::trapezoid_fill_for<F, SOA>();
     static constexpr bool streaming_stores = internal::streaming_stores_for<F, SOA>();
@@ -458,6 +481,11 @@ struct SweepGeometry {
     std::int32_t row_origin;            // global row of buffer row 0
     std::int32_t load_lo, load_hi;      // global rows present in the source buffers
     std::int32_t out_begin, out_end;    // global rows to produce
+    // columns (a buffer of a 2-D block decomposition holds a column range of the grid; whole rows otherwise:
+    // col_origin = 0, col_lo = 0, col_hi = grid_w, out columns = all)
+    std::int32_t col_origin;            // global column of buffer column 0
+    std::int32_t col_lo, col_hi;        // global columns present in the source buffers (inside the grid)
+    std::int32_t out_col_begin, out_col_end; // global columns to produce
     std::int32_t chunk_rows;            // rows of output per unit of the wave grid
     std::uint32_t n_strips, n_chunks;   // wave grid, in units (a wave, or the workgroup of a staged sweep)
     // The last units of the grid (dispatched last) take shorter chunks, so that the ragged end of a
@@ -596,16 +624,19 @@ struct Sweep {
         // (read where the kernel's arguments lie: indexing the tier tables at run time must not cost a private copy)
         SweepGeometry const &g = *(SweepGeometry const *)(const SweepGeometry __attribute__((address_space(4))) *)(
             (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(Args, geo));
-        const int x0 = strip * OW - GX + lane * K; // global column of the lane's first cell
+        const int x0 = g.out_col_begin + strip * OW - GX + lane * K; // global column of the lane's first cell
         const int ystart = ya - G;
         const int y_load_end = yb + G < g.load_hi ? yb + G : g.load_hi;
 
         bool col_in[K];
 #pragma unroll
         for (int k = 0; k < K; k++)
-            col_in[k] = unsigned(x0 + k) < unsigned(g.grid_w);
-        const bool vec_in = x0 >= 0 && x0 + K <= g.grid_w;
+            col_in[k] = unsigned(x0 + k - g.col_lo) < unsigned(g.col_hi - g.col_lo);
+        // (columns of the grid the buffers do not hold -- beyond the ghost columns of a block -- are treated like
+        // columns outside the grid: never loaded; they cannot reach a column this launch stores)
+        const bool vec_in = x0 >= g.col_lo && x0 + K <= g.col_hi;
         const bool lane_stores = lane * K >= GX && lane * K + K <= LW - GX;
+        const bool vec_out = vec_in && x0 + K <= g.out_col_end; // the last strip of a column range may be ragged
 
         // The launch's time-dependent values: the call's device table, or the kernel arguments (Args::tdv sits at
         // offset 0 of the kernel's argument segment).  Both are read through the constant address space -- nothing
@@ -646,7 +677,7 @@ struct Sweep {
             int yc = y < g.load_lo ? g.load_lo : y;
             yc = yc < y_load_end ? yc : y_load_end - 1;
             const std::size_t first =
-                row_offset(g, yc) + std::size_t(std::int64_t(x0));
+                row_offset(g, yc) + std::size_t(std::int64_t(x0 - g.col_origin));
             if constexpr (!EDGE) {
                 a.src.template load<K>(first, into);
             } else {
@@ -809,13 +840,13 @@ struct Sweep {
                     const int j = y - G; // row leaving the last level
                     if ((!FILLING || live) && j >= ya && j < yb && lane_stores) {
                         const std::size_t first =
-                            row_offset(g, j) + std::size_t(std::int64_t(x0));
-                        if (!EDGE || vec_in) {
+                            row_offset(g, j) + std::size_t(std::int64_t(x0 - g.col_origin));
+                        if (!EDGE || vec_out) {
                             a.dst.template store<K, streaming_stores_for<F, SOA>(), skip_mask>(first, cur);
                         } else {
 #pragma unroll
                             for (int k = 0; k < K; k++)
-                                if (col_in[k])
+                                if (col_in[k] && x0 + k < g.out_col_end)
                                     a.dst.template store_one<skip_mask>(first + k, cur[k]);
                         }
                     }
@@ -869,6 +900,14 @@ struct Sweep {
             super_step(t, std::false_type{});
     }
 
+    // The kernel's argument block where it lies (the kernel-argument segment, constant address space).  The device code
+    // reads everything from here and never touches the by-value parameter: where the optimiser could not take that
+    // copy apart it lived in private memory (64-80 bytes of scratch per lane in the L = 1 Jacobi kernels and two HotSpot
+    // depths, every plane pointer re-loaded from scratch in the edge code: tools/kernel_resources.sh).
+    STST_DEVICE __attribute__((always_inline)) static Args const &kernel_arguments() {
+        return *(Args const *)(const Args __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    }
+
     template <bool SKIP_CONSTANTS = false>
     STST_DEVICE __attribute__((always_inline)) static void entry(Args const &a, std::uint32_t *lds) {
         // (read where the kernel's arguments lie: indexing the tier tables at run time must not cost a private copy)
@@ -907,10 +946,11 @@ struct Sweep {
         int yb = ya + g.tier_rows[tier];
         yb = yb < g.out_end ? yb : g.out_end;
 
-        const int xw0 = strip * OW - GX; // footprint of the unit
-        // (xw0 > 0, not >= 0: the check-free code tells the transition function that its column is positive)
-        const bool interior =
-            INTERIOR_VARIANT && xw0 > 0 && xw0 + LW <= g.grid_w && ya - G >= 0 && yb + G <= g.grid_h;
+        const int xw0 = g.out_col_begin + strip * OW - GX; // footprint of the unit
+        // (xw0 > 0, not >= 0: the check-free code tells the transition function that its column is positive; col_lo and
+        // col_hi lie inside the grid; the strip's columns must all be columns to produce)
+        const bool interior = INTERIOR_VARIANT && xw0 > 0 && xw0 >= g.col_lo && xw0 + LW <= g.col_hi &&
+                              xw0 + LW - GX <= g.out_col_end && ya - G >= 0 && yb + G <= g.grid_h;
         // the stage of a wave is a compile-time property of the code it runs (levels, iteration and sub-iteration
         // indices, fused forms): one instantiation per stage, selected by the wave's index in the workgroup
         static_for<0, W>([&](auto sg) __attribute__((always_inline)) {
@@ -945,7 +985,7 @@ template <typename SW, int MIN_WAVES = 1, bool SKIP_CONSTANTS = false>
 __global__ void __launch_bounds__(SW::block_waves * wave_size, MIN_WAVES) sweep_kernel(const typename SW::Args args) {
     // the row rings between the stages of a staged sweep (one word otherwise)
     __shared__ __attribute__((aligned(16))) std::uint32_t rings[SW::LDS_WORDS];
-    SW::template entry<SKIP_CONSTANTS>(args, rings);
+    SW::template entry<SKIP_CONSTANTS>(SW::kernel_arguments(), rings); // `args` itself is not touched (see there)
 }
 
 // ------------------------------------------------------------------ host side
@@ -1089,6 +1129,22 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
                                                     dom.row_origin + std::int64_t(dom.local_rows)));
     g.out_begin = std::int32_t(out_begin);
     g.out_end = std::int32_t(out_end);
+    // columns: whole rows unless the buffers are a block of a 2-D decomposition (ststhip_domain::local_cols) and / or
+    // the driver has named a column range for this thread's launches (ststhip_set_launch_columns)
+    const std::int64_t local_cols = dom.local_cols ? std::int64_t(dom.local_cols) : std::int64_t(dom.global_width);
+    g.col_origin = std::int32_t(dom.local_cols ? dom.col_origin : 0);
+    g.col_lo = std::int32_t(std::max<std::int64_t>(0, g.col_origin));
+    g.col_hi = std::int32_t(std::min<std::int64_t>(std::int64_t(dom.global_width), std::int64_t(g.col_origin) + local_cols));
+    std::uint64_t col_begin = 0, col_end = 0;
+    ststhip_launch_columns(&col_begin, &col_end);
+    if (col_begin == col_end) {
+        col_begin = std::uint64_t(g.col_lo);
+        col_end = std::uint64_t(g.col_hi);
+    }
+    if (col_end <= col_begin || std::int64_t(col_begin) < g.col_lo || std::int64_t(col_end) > g.col_hi)
+        throw std::invalid_argument("the launch's column range must lie inside the columns the buffers hold");
+    g.out_col_begin = std::int32_t(col_begin);
+    g.out_col_end = std::int32_t(col_end);
     const void *kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd>);
     // per kernel instantiation; a property of the code object and the architecture, so racing host
     // threads would store the same number
@@ -1102,7 +1158,7 @@ void launch_sweep(F const &f, typename F::Cell const &halo, typename F::TimeDepe
     if constexpr (SOA && constant_plane_mask<F>() != 0)
         if (ststhip_target_holds_constants() && opt.skip_constant_stores)
             kernel = reinterpret_cast<const void *>(&sweep_kernel<SW, Tuning::min_waves_per_simd, true>);
-    g.n_strips = unsigned((dom.global_width + SW::OW - 1) / SW::OW); // units: waves, or workgroups (staged)
+    g.n_strips = unsigned((col_end - col_begin + SW::OW - 1) / SW::OW); // units: waves, or workgroups (staged)
     // rows a unit spends besides its output: 2G warm-up rows, and the skew of a staged pipeline (stage s starts s
     // batches late)
     const int overhead_rows = 2 * SW::G + (SW::W - 1) * SW::prefetch_depth;
@@ -1187,7 +1243,7 @@ void dispatch_sweep(int n_generations, F const &f, typename F::Cell const &halo,
 
 // Largest compiled depth that fits into `remaining` generations.
 template <typename F, bool SOA> inline int next_pass_depth(std::uint64_t remaining) {
-    int t = SweepTuning<F, SOA>::max_generations;
+    int t = default_generations_for<F, SOA>();
     const int cap = options().max_generations > 0 ? options().max_generations : t;
     while (t > 1 && (std::uint64_t(t) > remaining || t > cap))
         t /= 2;

@@ -139,6 +139,12 @@ int ststhip_set_launch_concurrency(int n_launches_side_by_side);
  * themselves: set it, launch over [top of the upper band, end of the lower band), reset it with (0, 0). */
 int ststhip_launch_row_hole(uint64_t *begin, uint64_t *end);
 int ststhip_set_launch_row_hole(uint64_t begin, uint64_t end);
+/* The global columns [begin, end) the calling thread's next sweep launches produce (begin == end: all columns the
+ * buffers hold inside the grid, the state outside of a driver).  The block driver (ststhip_block_*) names the owned
+ * columns of a block, widened by what the rest of a launch group still needs, this way; the row range stays an
+ * argument of the launch.  Every launch through hip/internal/Sweep.hpp's launch_sweep honours it. */
+int ststhip_launch_columns(uint64_t *begin, uint64_t *end);
+int ststhip_set_launch_columns(uint64_t begin, uint64_t end);
 /* Into how many row strips (1 or 2) a caller that advances `rows` x `width` cells of `app` for
  * `n_passes` launches should split them, each strip on its own stream and coupled to its
  * neighbours through halo-deep boundary bands only: the rule ststhip_run_passes applies to a whole
@@ -167,7 +173,9 @@ typedef struct {
     int32_t jacobi_fastpath, conway_fastpath;
     int32_t prepare_streams;       /* create and first-use the pass driver's streams at ststhip_init      */
     int32_t host_cache_mib;        /* free pinned host blocks kept for reuse                              */
-    int32_t reserved0;
+    int32_t tune_depth;            /* pass driver, families with two candidate depths (ststhip_sweep_desc::alt_generations):
+                                      1 (default) = time both on the first long call for a grid shape and keep the faster;
+                                      0 = always the trusted depth; N >= 2 = depth N outright                         */
     int32_t exchange_every;        /* strip driver: exchange m*g ghost rows every m-th launch; 0/1 = every launch */
     int32_t reserved1;
     int32_t reserved[6];
@@ -216,7 +224,13 @@ typedef struct {
     uint64_t global_width;  /* stencil.grid_range[1]                              */
     int64_t row_origin;     /* global row index of buffer row 0                   */
     uint64_t local_rows;    /* rows held by the buffers                           */
-    uint64_t pitch;         /* elements between consecutive rows (>= global_width) */
+    uint64_t pitch;         /* elements between consecutive rows (>= the columns held) */
+    /* ABI 5: a block of a 2-D decomposition holds a column range too.  local_cols = 0: whole rows (columns
+     * 0 .. global_width, the case of everything above); else buffer column 0 is global column `col_origin` (may be
+     * negative for the first block of a row: columns before global column 0 are never read) and the buffers hold
+     * `local_cols` columns: the owned ones plus ghost columns on both sides. */
+    int64_t col_origin;
+    uint64_t local_cols;
 } ststhip_domain;
 
 /* Static description of a precompiled transition function. */
@@ -236,6 +250,8 @@ typedef struct {
     uint32_t cells_per_lane;     /* adjacent cells a lane holds per row (K)              */
     uint32_t prefetch_rows;      /* rows loaded ahead of the pipeline (P)                */
     uint32_t stages;             /* waves of a workgroup that share one column strip as a pipeline over the levels (1 = independent waves) */
+    uint32_t default_generations; /* depth of launches nobody has measured (= max_generations unless the function's
+                                     tuning compiles a deeper family than it trusts: ststhip_sweep_desc::alt_generations) */
 } ststhip_app_info;
 
 int ststhip_app_count(void);
@@ -300,11 +316,30 @@ typedef struct {
     uint64_t tdv_size;
     void (*fill_tdv)(void *ctx, uint64_t iteration_offset, uint64_t n_iterations, void *values);
     const void *tdv_device_table;
+    /* Depth by measurement (ABI 5; 0 / 0: none).  The deepest compiled depth is not the fastest for every function and
+     * grid: what a transition function costs per cell is opaque to the rule that sizes the pipeline from the cell (the
+     * same five-point Jacobi source is nine operations per cell compiled with -ffp-contract=off and five with fused
+     * multiply-adds: the first is fastest at 8 generations per launch, the second at 16), and a small grid pays more
+     * for deep halos than a large one.  `alt_generations` names a second depth `sweep` accepts (a repeated halving of
+     * max_generations) and is the depth of every launch nobody has measured; on the first call for a grid shape that is
+     * long enough (>= 6 launches of max_generations) the pass driver times two launches of max_generations against the
+     * same generations at alt_generations -- these are the call's own first passes, no work is repeated --, keeps the
+     * faster for the rest of the call and, per (tune_key, height, width), for the process
+     * (ststhip_tuned_depth reads the choice).  Results do not depend on it.  `tune_key` identifies the kernel family
+     * (e.g. the address of the launch callback). */
+    uint32_t alt_generations;
+    uint32_t reserved;
+    uint64_t tune_key;
 } ststhip_sweep_desc;
 int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc,
                        const ststhip_domain *dom, const void *const *src, void *const *dst,
                        uint64_t iteration_offset, uint64_t n_iterations, int blocking, int profiling,
                        ststhip_stream stream, ststhip_run_info *info);
+/* The depth the pass driver has measured to be the faster one for (tune_key, height, width) in this process; 0 = not
+ * measured yet. */
+int ststhip_tuned_depth(uint64_t tune_key, uint64_t height, uint64_t width, uint32_t *depth);
+/* The same for a precompiled transition function (its kernel family's key is internal to the registry). */
+int ststhip_app_tuned_depth(const char *app, uint64_t height, uint64_t width, uint32_t *depth);
 
 /* Parameter blocks of the precompiled transition functions (plain data, host side). */
 typedef struct {
@@ -346,6 +381,11 @@ int ststhip_comm_destroy(ststhip_comm comm);
  * exchange path (dlopen'ed symbols, byte counts, pointer arithmetic, stream order) without a second device. */
 int ststhip_comm_set_neighbours(ststhip_comm comm, int up, int down);
 int ststhip_comm_neighbours(ststhip_comm comm, int *up, int *down);
+/* The same for the ghost COLUMNS of a 2-D block decomposition (ststhip_block_*): `left` holds the columns before this
+ * rank's, `right` those after; default -1 / -1.  ststhip_comm_set_mesh wires all four sides for ranks laid out
+ * row-major on a mesh_rows x mesh_cols mesh (rank = mesh_row * mesh_cols + mesh_col; mesh_rows * mesh_cols = n_ranks). */
+int ststhip_comm_set_column_neighbours(ststhip_comm comm, int left, int right);
+int ststhip_comm_set_mesh(ststhip_comm comm, int mesh_rows, int mesh_cols);
 /* For every plane p: send `n_rows` rows starting at send_up[p] to the upper neighbour (rank-1 unless set otherwise)
  * and at send_down[p] to the lower one (rank+1), receive into recv_up[p] (from the upper neighbour) and recv_down[p]
  * (from the lower one).  row_bytes[p] = bytes of one row of plane p.  Ranks without a neighbour on a side skip it. */
@@ -353,6 +393,13 @@ int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *cons
                                const void *const *send_down, void *const *recv_up,
                                void *const *recv_down, const size_t *row_bytes, size_t n_rows,
                                ststhip_stream stream);
+
+/* For every plane p: send the contiguous block of block_bytes[p] bytes at send_left[p] to the left neighbour and the
+ * one at send_right[p] to the right one, receive into recv_left[p] / recv_right[p] (the packed ghost columns of a 2-D
+ * block: the block driver packs and unpacks them with small copy kernels). */
+int ststhip_comm_exchange_columns(ststhip_comm comm, int n_planes, const void *const *send_left,
+                                  const void *const *send_right, void *const *recv_left, void *const *recv_right,
+                                  const size_t *block_bytes, ststhip_stream stream);
 
 /* ------------------------------------------------- row-strip driver (one strip per process / GPU)
  * The grid is cut into n_ranks strips of consecutive rows; every process owns one strip on its GPU and keeps it,
@@ -403,6 +450,31 @@ int ststhip_strip_warm_up(ststhip_strip strip);
 /* Advance the whole distributed grid by n_generations generations (every rank calls it with the same arguments). */
 int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64_t n_generations, int blocking);
 int ststhip_strip_counters(ststhip_strip strip, uint64_t *n_launches, uint64_t *n_exchanges);
+
+/* ------------------------------------------------- 2-D block decomposition (one block per process / GPU)
+ * The grid is cut into mesh_rows x mesh_cols blocks, rank = mesh_row * mesh_cols + mesh_col.  Every process keeps its
+ * block with ghost rows AND ghost columns in two buffer sets; the handle is an ststhip_strip: ststhip_strip_advance /
+ * _synchronize / _warm_up / _counters / _destroy / _stream work on it.  Per group of launches (STSTHIP_EXCHANGE_EVERY)
+ * the ghost cells travel in two phases on the comm stream -- columns first (strided in memory: packed into contiguous
+ * staging buffers by a copy kernel, sent, unpacked), then rows over the full buffer width, ghost columns included, which
+ * carries the corners --, then every launch of the group sweeps the owned block widened by what the rest of the group
+ * still needs.  The minimal form of the reference's tile geometry (StencilStream/tiling/Grid.hpp:305-450): no overlap of
+ * exchange and interior (a block's boundary is a frame, not two bands).  mesh_cols = 1 gives the row strips above
+ * without their overlap; use ststhip_strip_create for those.
+ * `comm`: a communicator of the mesh's ranks whose neighbours are wired for the mesh (ststhip_comm_set_mesh), or
+ * NULL and the two callbacks (contract of ststhip_comm_exchange_rows; the column callback gets the packed blocks as
+ * "one row" of block bytes: send_up = send_left, send_down = send_right, ...). */
+int ststhip_block_create(const char *app, const void *tf_params, const void *halo_cell, uint64_t total_rows,
+                         uint64_t total_cols, int rank, int mesh_rows, int mesh_cols, ststhip_comm comm,
+                         ststhip_exchange_fn exchange_rows, void *exchange_rows_ctx,
+                         ststhip_exchange_fn exchange_cols, void *exchange_cols_ctx, ststhip_strip *block);
+/* global rows and columns this block owns */
+int ststhip_block_geometry(ststhip_strip block, uint64_t *row_begin, uint64_t *row_end, uint64_t *col_begin,
+                           uint64_t *col_end);
+/* Copy the owned cells of plane `plane` of the current buffer set from / to host memory whose rows are
+ * `host_pitch_bytes` apart (2-D copies on the block's stream; both synchronise it before returning). */
+int ststhip_block_upload(ststhip_strip block, unsigned plane, const void *host_cells, size_t host_pitch_bytes);
+int ststhip_block_download(ststhip_strip block, unsigned plane, void *host_cells, size_t host_pitch_bytes);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,8 @@ class Domain(C.Structure):
         ("row_origin", C.c_int64),
         ("local_rows", C.c_uint64),
         ("pitch", C.c_uint64),
+        ("col_origin", C.c_int64),   # ABI 5: a block of a 2-D decomposition; local_cols = 0: whole rows
+        ("local_cols", C.c_uint64),
     ]
 
 
@@ -59,6 +61,7 @@ class AppInfo(C.Structure):
         ("cells_per_lane", C.c_uint32),
         ("prefetch_rows", C.c_uint32),
         ("stages", C.c_uint32),
+        ("default_generations", C.c_uint32),
     ]
 
 
@@ -133,7 +136,7 @@ class Options(C.Structure):
                    "max_generations", "allow_spilling_depths", "virtual_strips", "two_strips_permille",
                    "two_strips_permille_outer", "strip_skew_permille", "bands_beside_interior", "band_stream_priority",
                    "bands_apart", "bands_one_launch", "comm_stream_priority", "jacobi_fastpath", "conway_fastpath",
-                   "prepare_streams", "host_cache_mib", "reserved0", "exchange_every", "reserved1")] + \
+                   "prepare_streams", "host_cache_mib", "tune_depth", "exchange_every", "reserved1")] + \
                [("reserved", C.c_int32 * 6)]
 
 
@@ -198,6 +201,8 @@ def load():
         "ststhip_set_launch_concurrency": [C.c_int],
         "ststhip_launch_row_hole": [C.POINTER(u64), C.POINTER(u64)],
         "ststhip_set_launch_row_hole": [u64, u64],
+        "ststhip_launch_columns": [C.POINTER(u64), C.POINTER(u64)],
+        "ststhip_set_launch_columns": [u64, u64],
         "ststhip_suggest_row_strips": [C.c_char_p, u64, u64, u64],
         "ststhip_scatter_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
         "ststhip_gather_fields": [vp, sz, sz, C.c_int, C.POINTER(sz), C.POINTER(sz), pp, vp],
@@ -210,11 +215,20 @@ def load():
                             vp, C.POINTER(RunInfo)],
         "ststhip_run_passes": [vp, vp, vp, C.POINTER(Domain), pp, pp, u64, u64, C.c_int, C.c_int, vp,
                                C.POINTER(RunInfo)],
+        "ststhip_tuned_depth": [u64, u64, u64, C.POINTER(u32)],
+        "ststhip_app_tuned_depth": [C.c_char_p, u64, u64, C.POINTER(u32)],
         "ststhip_comm_unique_id": [C.c_char_p],
         "ststhip_comm_create": [C.c_char_p, C.c_int, C.c_int, pp],
         "ststhip_comm_destroy": [vp],
         "ststhip_comm_set_neighbours": [vp, C.c_int, C.c_int],
         "ststhip_comm_neighbours": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "ststhip_comm_set_column_neighbours": [vp, C.c_int, C.c_int],
+        "ststhip_comm_set_mesh": [vp, C.c_int, C.c_int],
+        "ststhip_comm_exchange_columns": [vp, C.c_int, pp, pp, pp, pp, C.POINTER(sz), vp],
+        "ststhip_block_create": [C.c_char_p, vp, vp, u64, u64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, pp],
+        "ststhip_block_geometry": [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)],
+        "ststhip_block_upload": [vp, C.c_uint, vp, sz],
+        "ststhip_block_download": [vp, C.c_uint, vp, sz],
         "ststhip_comm_exchange_rows": [vp, C.c_int, pp, pp, pp, pp, C.POINTER(sz), sz, vp],
         "ststhip_strip_create": [C.c_char_p, vp, vp, u64, u64, C.c_int, C.c_int, vp, vp, vp, pp],
         "ststhip_strip_create_custom": [vp, vp, vp, u64, u64, C.c_int, C.c_int, vp, vp, vp, pp],
@@ -371,6 +385,13 @@ def app_run(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, iteration_offse
         f"ststhip_app_run({app})",
     )
     return info
+
+
+def app_tuned_depth(app, height, width):
+    """Blocking depth the pass driver has measured to be the faster one for this app and grid shape (0: not measured)."""
+    depth = C.c_uint32()
+    check(load().ststhip_app_tuned_depth(app.encode(), int(height), int(width), C.byref(depth)), "ststhip_app_tuned_depth")
+    return int(depth.value)
 
 
 def set_launch_concurrency(n):
@@ -537,6 +558,73 @@ class Strip:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+def _exchange_trampoline(exchange):
+    """A Python exchange callable behind the ststhip_exchange_fn signature."""
+    def trampoline(_ctx, n_planes, su, sd, ru, rd, rb, n_rows, stream):
+        try:
+            exchange(n_planes, [su[i] for i in range(n_planes)], [sd[i] for i in range(n_planes)],
+                     [ru[i] for i in range(n_planes)], [rd[i] for i in range(n_planes)],
+                     [rb[i] for i in range(n_planes)], int(n_rows), stream)
+            return 0
+        except Exception as e:  # noqa: BLE001 -- reported through the C ABI's status
+            load().ststhip_set_last_error(str(e).encode())
+            return 5
+    return EXCHANGE_FN(trampoline)
+
+
+def comm_set_mesh(comm, mesh_rows, mesh_cols):
+    check(load().ststhip_comm_set_mesh(comm, int(mesh_rows), int(mesh_cols)), "ststhip_comm_set_mesh")
+
+
+def comm_set_column_neighbours(comm, left, right):
+    check(load().ststhip_comm_set_column_neighbours(comm, int(left), int(right)), "ststhip_comm_set_column_neighbours")
+
+
+class Block(Strip):
+    """One block of a grid cut into mesh_rows x mesh_cols blocks (ststhip_block_*), one process per block.
+
+    comm: a communicator of the mesh's ranks wired with comm_set_mesh(); or exchange_rows / exchange_cols: Python
+    callables with the signature of Strip's `exchange` (the column callable gets the packed ghost columns as one "row"
+    per plane: send_up = to the left, send_down = to the right)."""
+
+    def __init__(self, app, tf_params, halo_bytes, total_rows, total_cols, rank, mesh_rows, mesh_cols, comm=None,
+                 exchange_rows=None, exchange_cols=None):
+        _sync_options()
+        self._callback = _exchange_trampoline(exchange_rows) if exchange_rows is not None else None
+        self._callback_cols = _exchange_trampoline(exchange_cols) if exchange_cols is not None else None
+        halo = C.create_string_buffer(bytes(halo_bytes), len(halo_bytes))
+        self.handle = C.c_void_p()
+        self.tf_params = tf_params
+        as_ptr = lambda cb: C.cast(cb, C.c_void_p) if cb is not None else None  # noqa: E731
+        check(load().ststhip_block_create(app.encode(), C.cast(C.byref(tf_params), C.c_void_p), C.cast(halo, C.c_void_p),
+                                          int(total_rows), int(total_cols), int(rank), int(mesh_rows), int(mesh_cols), comm,
+                                          as_ptr(self._callback), None, as_ptr(self._callback_cols), None,
+                                          C.byref(self.handle)), f"ststhip_block_create({app})")
+        r0, r1, c0, c1 = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(load().ststhip_block_geometry(self.handle, C.byref(r0), C.byref(r1), C.byref(c0), C.byref(c1)),
+              "ststhip_block_geometry")
+        self.row_begin, self.row_end, self.col_begin, self.col_end = (int(v.value) for v in (r0, r1, c0, c1))
+        s = C.c_void_p()
+        check(load().ststhip_strip_stream(self.handle, C.byref(s)), "ststhip_strip_stream")
+        self.stream = s.value
+
+    def upload(self, index, host_array):
+        import numpy as np
+
+        cells = np.ascontiguousarray(host_array)
+        assert cells.shape[0] == self.row_end - self.row_begin, "array does not match the block's rows"
+        check(load().ststhip_block_upload(self.handle, index, cells.ctypes.data_as(C.c_void_p), cells.strides[0]),
+              "ststhip_block_upload")
+
+    def download(self, index, dtype):
+        import numpy as np
+
+        out = np.empty((self.row_end - self.row_begin, self.col_end - self.col_begin), dtype=dtype)
+        check(load().ststhip_block_download(self.handle, index, out.ctypes.data_as(C.c_void_p), out.strides[0]),
+              "ststhip_block_download")
+        return out
 
 
 def scatter_fields(aos_ptr, cell_size, n_cells, offsets, sizes, plane_ptrs, stream=0):

@@ -30,13 +30,25 @@ using K5 = KERNEL(Constant5);
 using K6 = KERNEL(General4);
 using K7 = KERNEL(General5);
 using K8 = KERNEL(General9);
+// JACOBI_SET = 0 .. 3: the variants are compiled in four translation units side by side (each one-word variant is a
+// family of five depths in two lane widths: one unit took a quarter of an hour)
+#ifndef JACOBI_SET
+#define JACOBI_SET 0
+#endif
 #ifndef STSTHIP_FMA_FLAVOUR
+#if JACOBI_SET == 1
 STSTHIP_REGISTER_APP(NAME("jacobi1general"), K1, false);
 STSTHIP_REGISTER_APP(NAME("jacobi2constant"), K2, false);
+#elif JACOBI_SET == 2
 STSTHIP_REGISTER_APP(NAME("jacobi3constant"), K3, false);
 STSTHIP_REGISTER_APP(NAME("jacobi4constant"), K4, false);
+#elif JACOBI_SET == 3
 STSTHIP_REGISTER_APP(NAME("jacobi5constant"), K5, false);
 STSTHIP_REGISTER_APP(NAME("jacobi4general"), K6, false);
+#else
 STSTHIP_REGISTER_APP(NAME("jacobi9general"), K8, false);
 #endif
+#endif
+#if JACOBI_SET == 0
 STSTHIP_REGISTER_APP(NAME("jacobi5general"), K7, false);
+#endif

@@ -98,6 +98,7 @@ template <typename F, bool SOA> struct AppAdapter {
         e.info.cells_per_lane = std::uint32_t(Tuning::cells_per_lane);
         e.info.prefetch_rows = std::uint32_t(Tuning::prefetch_rows);
         e.info.stages = std::uint32_t(stencil::hip::internal::SweepOf<F, SOA>::W);
+        e.info.default_generations = std::uint32_t(stencil::hip::internal::default_generations_for<F, SOA>());
         e.sweep = &sweep;
         e.fill_tdv = e.info.tdv_size ? &fill_tdv : nullptr;
         return e;

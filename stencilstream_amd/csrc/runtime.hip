@@ -14,6 +14,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace ststhip_detail {
@@ -80,6 +81,7 @@ static ststhip_options read_options() {
     o.prepare_streams = env_int("STSTHIP_PREPARE_STREAMS", 1);
     o.host_cache_mib = env_int("STSTHIP_HOST_CACHE_MIB", 4096);
     o.exchange_every = env_int("STSTHIP_EXCHANGE_EVERY", 0);
+    o.tune_depth = env_int("STSTHIP_TUNE_DEPTH", 1);
     return o;
 }
 static ststhip_options &options_storage() {
@@ -509,6 +511,7 @@ struct Comm {
     void *nccl = nullptr;
     int rank = 0, n_ranks = 1;
     int up = -1, down = -1; // ranks the ghost rows are exchanged with (-1: none); a chain of strips by default
+    int left = -1, right = -1; // ranks the ghost columns of a 2-D block are exchanged with (-1: none)
 };
 
 } // namespace ststhip_detail
@@ -923,6 +926,21 @@ int ststhip_set_launch_row_hole(uint64_t begin, uint64_t end) {
     g_row_hole_end = end;
     return STSTHIP_OK;
 }
+static thread_local std::uint64_t g_col_begin = 0, g_col_end = 0;
+int ststhip_launch_columns(uint64_t *begin, uint64_t *end) {
+    if (begin)
+        *begin = g_col_begin;
+    if (end)
+        *end = g_col_end;
+    return STSTHIP_OK;
+}
+int ststhip_set_launch_columns(uint64_t begin, uint64_t end) {
+    if (end < begin)
+        return fail(STSTHIP_ERR_INVALID, "bad column range");
+    g_col_begin = begin;
+    g_col_end = end;
+    return STSTHIP_OK;
+}
 int ststhip_target_holds_constants(void) { return g_target_holds_constants; }
 int ststhip_set_launch_concurrency(int n) {
     g_launch_concurrency = std::min(std::max(n, 1), 8);
@@ -1078,8 +1096,8 @@ static int check_domain(const AppEntry *e, const ststhip_domain *dom, std::uint6
                         std::uint64_t out_end, std::uint32_t n_generations) {
     if (!dom)
         return fail(STSTHIP_ERR_INVALID, "null domain");
-    if (dom->pitch < dom->global_width)
-        return fail(STSTHIP_ERR_INVALID, "pitch smaller than the grid width");
+    if (dom->pitch < (dom->local_cols ? dom->local_cols : dom->global_width))
+        return fail(STSTHIP_ERR_INVALID, "pitch smaller than the columns the buffers hold");
     if (out_end > dom->global_height || out_begin > out_end)
         return fail(STSTHIP_ERR_INVALID, "output rows outside the grid");
     // compiled depths: max_generations and its repeated halvings
@@ -1098,6 +1116,21 @@ static int check_domain(const AppEntry *e, const ststhip_domain *dom, std::uint6
     if (out_end > out_begin &&
         (need_lo < dom->row_origin || need_hi > dom->row_origin + std::int64_t(dom->local_rows)))
         return fail(STSTHIP_ERR_INVALID, "buffers do not hold the ghost rows this sweep reads");
+    // the same for the columns of a block (whole rows: nothing to check)
+    if (dom->local_cols) {
+        const std::int64_t held_lo = std::max<std::int64_t>(0, dom->col_origin);
+        const std::int64_t held_hi = std::min<std::int64_t>(std::int64_t(dom->global_width),
+                                                            dom->col_origin + std::int64_t(dom->local_cols));
+        std::int64_t cb = std::int64_t(g_col_begin), ce = std::int64_t(g_col_end);
+        if (cb == ce) {
+            cb = held_lo;
+            ce = held_hi;
+        }
+        const std::int64_t want_lo = std::max<std::int64_t>(0, cb - g);
+        const std::int64_t want_hi = std::min<std::int64_t>(std::int64_t(dom->global_width), ce + g);
+        if (cb < held_lo || ce > held_hi || ((cb != held_lo || ce != held_hi) && (want_lo < held_lo || want_hi > held_hi)))
+            return fail(STSTHIP_ERR_INVALID, "buffers do not hold the ghost columns this sweep reads");
+    }
     return STSTHIP_OK;
 }
 
@@ -1126,9 +1159,12 @@ int ststhip_app_sweep(const char *app, const void *tf_params, const void *halo_c
 // part of the chip idles (at 16384^2 a pass is only ~3 residency rounds long).  Splitting the rows
 // into V strips that advance on V streams, coupled only through their G-row boundary bands, lets
 // the tail of one strip's kernel overlap with the next kernels of the other strips.
-static std::vector<std::uint32_t> plan_depths(std::uint64_t n_iterations, std::uint32_t max_generations) {
+static std::vector<std::uint32_t> plan_depths(std::uint64_t n_iterations, std::uint32_t max_generations,
+                                              std::uint32_t depth_cap = 0) {
     std::vector<std::uint32_t> depths;
-    const int cap = opt().max_generations > 0 ? opt().max_generations : int(max_generations);
+    int cap = opt().max_generations > 0 ? opt().max_generations : int(max_generations);
+    if (depth_cap > 0)
+        cap = std::min(cap, int(depth_cap));
     std::uint64_t remaining = n_iterations;
     while (remaining > 0) {
         std::uint32_t t = max_generations;
@@ -1138,6 +1174,36 @@ static std::vector<std::uint32_t> plan_depths(std::uint64_t n_iterations, std::u
         remaining -= t;
     }
     return depths;
+}
+
+// Depths chosen by measurement (ststhip_sweep_desc::alt_generations), per kernel family and grid shape, for the process.
+extern "C++" {
+namespace {
+struct TunedKey {
+    std::uint64_t key, height, width;
+    bool operator<(TunedKey const &o) const { return std::tie(key, height, width) < std::tie(o.key, o.height, o.width); }
+};
+std::map<TunedKey, std::uint32_t> &tuned_depths() {
+    static std::map<TunedKey, std::uint32_t> m;
+    return m;
+}
+} // namespace
+} // extern "C++"
+
+int ststhip_tuned_depth(uint64_t tune_key, uint64_t height, uint64_t width, uint32_t *depth) {
+    if (!depth)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(rt().lock);
+    auto it = tuned_depths().find(TunedKey{tune_key, height, width});
+    *depth = it == tuned_depths().end() ? 0u : it->second;
+    return STSTHIP_OK;
+}
+
+int ststhip_app_tuned_depth(const char *app, uint64_t height, uint64_t width, uint32_t *depth) {
+    const AppEntry *e = find_app(app);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    return ststhip_tuned_depth(reinterpret_cast<std::uintptr_t>(e), height, width, depth);
 }
 
 int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc,
@@ -1158,7 +1224,54 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
     const std::uint64_t H = dom->global_height;
     auto started = std::chrono::high_resolution_clock::now();
 
-    const std::vector<std::uint32_t> depths = plan_depths(n_iterations, desc->max_generations);
+    // The depth plan.  With a second candidate depth (desc->alt_generations) the first call for a grid shape times its
+    // own first passes at both depths and keeps the faster (ststhip.h, ststhip_sweep_desc); later calls look it up.
+    const std::uint32_t deep = desc->max_generations, alt = desc->alt_generations;
+    const bool tunable = desc->tune_key != 0 && alt >= 2 && alt < deep && deep % alt == 0 && !profiling &&
+                         opt().tune_depth == 1 && opt().max_generations <= 0;
+    // (a family with a second depth runs it wherever nothing has been measured: that is the depth its rule trusts)
+    std::uint32_t depth_cap = (alt >= 1 && alt < deep) ? alt : 0;
+    bool probing = false;
+    // STSTHIP_TUNE_DEPTH >= 2 names the depth outright (profiling runs must plan the launches of the unprofiled run)
+    if (depth_cap && opt().tune_depth >= 2 && (std::uint32_t(opt().tune_depth) == alt || std::uint32_t(opt().tune_depth) == deep)) {
+        depth_cap = std::uint32_t(opt().tune_depth);
+    } else if (tunable) {
+        std::uint32_t known = 0;
+        ststhip_tuned_depth(desc->tune_key, H, dom->global_width, &known);
+        if (known)
+            depth_cap = known;
+        else
+            probing = n_iterations >= 6ull * deep;
+    }
+    std::vector<std::uint32_t> depths;
+    // a probing call: [deep (untimed: clocks and caches settle)] [deep, deep] [alt x 2*deep/alt] then the rest at the
+    // winner's depth, planned once the probes have been timed.  The ping-pong parity of the targets must be fixed
+    // before that: it is that of the plan that continues at `deep`; if the other plan wins with the other parity, one
+    // of its passes is split into two of half its depth.
+    const std::size_t probe_passes = probing ? 3 + 2 * (deep / alt) : 0;
+    std::vector<std::uint32_t> rest_alt;
+    if (probing) {
+        for (int i = 0; i < 3; i++)
+            depths.push_back(deep);
+        for (std::uint32_t i = 0; i < 2 * (deep / alt); i++)
+            depths.push_back(alt);
+        const std::uint64_t left = n_iterations - 5ull * deep;
+        const std::vector<std::uint32_t> rest_deep = plan_depths(left, deep);
+        rest_alt = plan_depths(left, deep, alt);
+        if ((rest_alt.size() + rest_deep.size()) % 2 != 0) {
+            // split the first pass of depth `alt` (there is one: left >= deep) into two of alt / 2
+            for (std::size_t i = 0; i < rest_alt.size(); i++)
+                if (rest_alt[i] == alt) {
+                    rest_alt[i] = alt / 2;
+                    rest_alt.insert(rest_alt.begin() + i, alt / 2);
+                    break;
+                }
+        }
+        depths.insert(depths.end(), rest_deep.begin(), rest_deep.end()); // replaced by rest_alt if alt wins
+    } else {
+        depths = plan_depths(n_iterations, deep, depth_cap);
+    }
+    hipEvent_t probe_events[3] = {nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
     EventPool sync_events;
     std::uint64_t n_launches = 0;
@@ -1172,7 +1285,8 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
     };
 
     // how many virtual strips: only worth it for grids with many rows per strip
-    const std::uint64_t g_max = std::uint64_t(desc->max_generations) * desc->halo_depth_per_generation;
+    const std::uint64_t g_max = std::uint64_t((!probing && depth_cap) ? std::min(deep, depth_cap) : deep) *
+                                desc->halo_depth_per_generation;
     int strips = profiling ? 1
                            : suggest_row_strips(H, dom->global_width, desc->strip_width, g_max, depths.size());
 
@@ -1258,7 +1372,48 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         // the last pass must land in dst; the input is never written
         const void *const *from = src;
         std::uint64_t iteration = iteration_offset;
+        // a point in time on every stream of the call: everything queued so far has finished before `ev`, nothing
+        // queued later starts before it (the boundaries of the depth probes' timed groups)
+        auto fence_all = [&](hipEvent_t ev) {
+            for (int v = 1; v < strips; v++)
+                ordered(hipStreamWaitEvent(s, [&] { hipEvent_t e = new_event(); ordered(hipEventRecord(e, lane[v]), "hipEventRecord"); return e; }(), 0),
+                        "hipStreamWaitEvent");
+            if (bands_beside)
+                for (int v = 0; v < strips; v++)
+                    ordered(hipStreamWaitEvent(s, [&] { hipEvent_t e = new_event(); ordered(hipEventRecord(e, band_lane[v]), "hipEventRecord"); return e; }(), 0),
+                            "hipStreamWaitEvent");
+            ordered(hipEventRecord(ev, s), "hipEventRecord");
+            for (int v = 1; v < strips; v++)
+                ordered(hipStreamWaitEvent(lane[v], ev, 0), "hipStreamWaitEvent");
+            if (bands_beside)
+                for (int v = 0; v < strips; v++)
+                    ordered(hipStreamWaitEvent(band_lane[v], ev, 0), "hipStreamWaitEvent");
+        };
+        if (probing)
+            for (hipEvent_t &ev : probe_events)
+                ordered(hipEventCreate(&ev), "hipEventCreate");
         for (std::size_t pass = 0; pass < depths.size() && rc == STSTHIP_OK; pass++) {
+            if (probing && (pass == 1 || pass == 3 || pass == probe_passes)) {
+                const int boundary = pass == 1 ? 0 : (pass == 3 ? 1 : 2);
+                fence_all(probe_events[boundary]);
+                if (boundary == 2) {
+                    // the host waits for the probes here (a few milliseconds, once per kernel family and grid shape)
+                    float ms_deep = 0.0f, ms_alt = 0.0f;
+                    ordered(hipEventSynchronize(probe_events[2]), "hipEventSynchronize");
+                    ordered(hipEventElapsedTime(&ms_deep, probe_events[0], probe_events[1]), "hipEventElapsedTime");
+                    ordered(hipEventElapsedTime(&ms_alt, probe_events[1], probe_events[2]), "hipEventElapsedTime");
+                    if (rc != STSTHIP_OK)
+                        break;
+                    // (the shallower depth has to win by 2 %: a tie keeps the plan that is already laid out)
+                    const bool take_alt = ms_alt < 0.98f * ms_deep;
+                    if (take_alt) {
+                        depths.resize(probe_passes);
+                        depths.insert(depths.end(), rest_alt.begin(), rest_alt.end());
+                    }
+                    std::lock_guard<std::mutex> guard(rt().lock);
+                    tuned_depths()[TunedKey{desc->tune_key, H, dom->global_width}] = take_alt ? alt : deep;
+                }
+            }
             const bool into_dst = ((depths.size() - 1 - pass) % 2) == 0;
             void *const *to = into_dst ? dst : scratch;
             // targets alternate, and every pass writes all rows: from the third pass on the target already holds
@@ -1355,6 +1510,9 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             ststhip_free_async(scratch[p], s);
     if (tdv_table)
         ststhip_free_async(tdv_table, s);
+    for (hipEvent_t ev : probe_events)
+        if (ev)
+            (void)hipEventDestroy(ev);
     double kernel_s = 0.0;
     for (auto &ev : timed) {
         float ms = 0.0f;
@@ -1472,7 +1630,7 @@ int resolve_app(ResolvedApp &r, const char *app, const void *tf_params, const vo
     }
     // Game of Life with a dead halo on a grid whose width and pitch are multiples of four cells: the same
     // rule on 32-bit words of four cells (apps/conway.hpp, ConwayPacked), swept as a grid of words
-    if (std::strcmp(app, "conway") == 0 && dom->global_width > 0 && dom->global_width % 4 == 0 &&
+    if (std::strcmp(app, "conway") == 0 && dom->local_cols == 0 && dom->global_width > 0 && dom->global_width % 4 == 0 &&
         dom->pitch % 4 == 0 && *static_cast<const unsigned char *>(halo_cell) == 0 &&
         (!have_planes || (reinterpret_cast<std::uintptr_t>(src[0]) % 4 == 0 &&
                           reinterpret_cast<std::uintptr_t>(dst[0]) % 4 == 0)) &&
@@ -1494,6 +1652,11 @@ int resolve_app(ResolvedApp &r, const char *app, const void *tf_params, const vo
     r.desc.strip_width = e->info.strip_width;
     for (unsigned p = 0; p < e->info.n_planes; p++)
         r.desc.plane_elem_size[p] = e->info.plane_elem_size[p];
+    // a family compiled deeper than its rule trusts: the unmeasured depth, and the key its measurements are kept under
+    if (e->info.default_generations > 0 && e->info.default_generations < e->info.max_generations) {
+        r.desc.alt_generations = e->info.default_generations;
+        r.desc.tune_key = reinterpret_cast<std::uintptr_t>(e);
+    }
     if (r.uniform) {
         r.trampoline = uniform_jacobi_trampoline;
         r.ctx = &r.uniform_call;
@@ -1519,8 +1682,8 @@ int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cel
         return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
     if (!tf_params || !halo_cell || !src || !dst || !dom)
         return fail(STSTHIP_ERR_INVALID, "null argument");
-    if (dom->pitch < dom->global_width)
-        return fail(STSTHIP_ERR_INVALID, "pitch smaller than the grid width");
+    if (dom->pitch < dom->global_width || dom->local_cols != 0)
+        return fail(STSTHIP_ERR_INVALID, "ststhip_app_run works on whole grids: pitch >= width, no column range");
     for (unsigned p = 0; p < e->info.n_planes; p++)
         if (!src[p] || !dst[p] || src[p] == dst[p])
             return fail(STSTHIP_ERR_INVALID, "source and target planes must be distinct non-null buffers");
@@ -1612,25 +1775,20 @@ int ststhip_comm_neighbours(ststhip_comm comm, int *up, int *down) {
     return STSTHIP_OK;
 }
 
-int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *const *send_up,
-                               const void *const *send_down, void *const *recv_up,
-                               void *const *recv_down, const size_t *row_bytes, size_t n_rows,
-                               ststhip_stream stream) {
-    Comm *c = static_cast<Comm *>(comm);
-    if (!c || n_planes < 1 || n_planes > 16 || !row_bytes)
-        return fail(STSTHIP_ERR_INVALID, "bad exchange arguments");
-    if (n_rows == 0)
-        return STSTHIP_OK;
-    hipStream_t s = resolve(stream);
+// Grouped send / receive with the two neighbours of one direction (`first`: the rank whose rows lie above / whose
+// columns lie to the left; `second`: below / to the right).
+// RCCL matches the messages between two ranks in the order they were posted.  Per plane: both sends, then the receive
+// from `second`, then the one from `first` -- so that when both name the SAME rank (two blocks of a ring, or a rank
+// that is its own neighbour: the one-GPU loopback of tests/test_strip_native_gpu.py) that rank's first-side data land
+// in the ghost cells on the receiver's second side and vice versa.  In a chain two ranks share one message per plane
+// and direction and any order would do.
+static int exchange_with(Comm *c, int first, int second, int n_planes, const void *const *send_first,
+                         const void *const *send_second, void *const *recv_first, void *const *recv_second,
+                         const size_t *bytes_per_unit, size_t n_units, hipStream_t s) {
     const int ncclChar = 0;
-    const bool has_up = c->up >= 0, has_down = c->down >= 0;
-    if ((has_up && (!send_up || !recv_up)) || (has_down && (!send_down || !recv_down)))
+    const bool has_first = first >= 0, has_second = second >= 0;
+    if ((has_first && (!send_first || !recv_first)) || (has_second && (!send_second || !recv_second)))
         return fail(STSTHIP_ERR_INVALID, "bad exchange arguments");
-    // RCCL matches the messages between two ranks in the order they were posted.  Per plane: both sends, then the
-    // receive from below, then the one from above -- so that when `up` and `down` name the SAME rank (two strips of
-    // a ring, or a rank that is its own neighbour: the one-GPU loopback of tests/test_strip_native_gpu.py) that
-    // rank's upper rows land in the ghost rows below the receiver's and its lower rows in those above.  In a chain
-    // two ranks share one message per plane and direction and any order would do.
     NCCL_TRY(rccl().GroupStart());
     int failed = 0; // a group that was opened is closed again whatever happens inside
     const char *what = "";
@@ -1641,15 +1799,15 @@ int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *cons
         }
     };
     for (int p = 0; p < n_planes && failed == 0; p++) {
-        const size_t bytes = row_bytes[p] * n_rows;
-        if (has_up)
-            post(rccl().Send(send_up[p], bytes, ncclChar, c->up, c->nccl, s), "ncclSend (up)");
-        if (has_down)
-            post(rccl().Send(send_down[p], bytes, ncclChar, c->down, c->nccl, s), "ncclSend (down)");
-        if (has_down)
-            post(rccl().Recv(recv_down[p], bytes, ncclChar, c->down, c->nccl, s), "ncclRecv (down)");
-        if (has_up)
-            post(rccl().Recv(recv_up[p], bytes, ncclChar, c->up, c->nccl, s), "ncclRecv (up)");
+        const size_t bytes = bytes_per_unit[p] * n_units;
+        if (has_first)
+            post(rccl().Send(send_first[p], bytes, ncclChar, first, c->nccl, s), "ncclSend (up / left)");
+        if (has_second)
+            post(rccl().Send(send_second[p], bytes, ncclChar, second, c->nccl, s), "ncclSend (down / right)");
+        if (has_second)
+            post(rccl().Recv(recv_second[p], bytes, ncclChar, second, c->nccl, s), "ncclRecv (down / right)");
+        if (has_first)
+            post(rccl().Recv(recv_first[p], bytes, ncclChar, first, c->nccl, s), "ncclRecv (up / left)");
     }
     const int ended = rccl().GroupEnd();
     if (failed != 0)
@@ -1657,6 +1815,50 @@ int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *cons
     if (ended != 0)
         return nccl_fail(ended, "ncclGroupEnd");
     return STSTHIP_OK;
+}
+
+int ststhip_comm_exchange_rows(ststhip_comm comm, int n_planes, const void *const *send_up,
+                               const void *const *send_down, void *const *recv_up,
+                               void *const *recv_down, const size_t *row_bytes, size_t n_rows,
+                               ststhip_stream stream) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c || n_planes < 1 || n_planes > 16 || !row_bytes)
+        return fail(STSTHIP_ERR_INVALID, "bad exchange arguments");
+    if (n_rows == 0)
+        return STSTHIP_OK;
+    return exchange_with(c, c->up, c->down, n_planes, send_up, send_down, recv_up, recv_down, row_bytes, n_rows,
+                         resolve(stream));
+}
+
+int ststhip_comm_set_column_neighbours(ststhip_comm comm, int left, int right) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c || left < -1 || right < -1 || left >= c->n_ranks || right >= c->n_ranks)
+        return fail(STSTHIP_ERR_INVALID, "neighbours must be ranks of the communicator, or -1");
+    c->left = left;
+    c->right = right;
+    return STSTHIP_OK;
+}
+
+int ststhip_comm_set_mesh(ststhip_comm comm, int mesh_rows, int mesh_cols) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c || mesh_rows < 1 || mesh_cols < 1 || mesh_rows * mesh_cols != c->n_ranks)
+        return fail(STSTHIP_ERR_INVALID, "the mesh must have exactly the communicator's ranks");
+    const int r = c->rank / mesh_cols, k = c->rank % mesh_cols;
+    c->up = r > 0 ? c->rank - mesh_cols : -1;
+    c->down = r + 1 < mesh_rows ? c->rank + mesh_cols : -1;
+    c->left = k > 0 ? c->rank - 1 : -1;
+    c->right = k + 1 < mesh_cols ? c->rank + 1 : -1;
+    return STSTHIP_OK;
+}
+
+int ststhip_comm_exchange_columns(ststhip_comm comm, int n_planes, const void *const *send_left,
+                                  const void *const *send_right, void *const *recv_left, void *const *recv_right,
+                                  const size_t *block_bytes, ststhip_stream stream) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c || n_planes < 1 || n_planes > 16 || !block_bytes)
+        return fail(STSTHIP_ERR_INVALID, "bad exchange arguments");
+    return exchange_with(c, c->left, c->right, n_planes, send_left, send_right, recv_left, recv_right, block_bytes, 1,
+                         resolve(stream));
 }
 
 
@@ -1682,6 +1884,14 @@ struct Strip {
     std::vector<hipStream_t> band; // the boundary bands' stream (highest priority), created when first needed
     ststhip_domain dom;        // geometry of the buffers (in words for the packed Game of Life)
     std::uint64_t n_launches = 0, n_exchanges = 0;
+    // a block of a 2-D decomposition (ststhip_block_create): a column range and ghost columns as well
+    bool is_block = false;
+    int mesh_rows = 1, mesh_cols = 1, mesh_r = 0, mesh_c = 0;
+    std::uint64_t total_cols = 0, col_begin = 0, col_end = 0, ghost_cols = 0, local_cols = 0;
+    std::int64_t col_origin = 0;
+    ststhip_exchange_fn exchange_cols = nullptr;
+    void *exchange_cols_ctx = nullptr;
+    void *stage[4][16] = {{nullptr}}; // packed ghost columns per plane: to the left, to the right, from the left, from the right
 };
 
 void strip_bounds(std::uint64_t total, int n, int r, std::uint64_t &a, std::uint64_t &b) {
@@ -1714,6 +1924,11 @@ int strip_exchange(Strip &st, int set, std::uint64_t g) {
     return st.exchange(st.exchange_ctx, int(st.n_planes), send_up, send_down, recv_up, recv_down, row_bytes,
                        std::size_t(g), st.comm_stream);
 }
+// the 2-D block driver (below)
+extern "C++" {
+int block_exchange(Strip &st, int set, std::uint64_t g);
+int block_advance(Strip *st, std::uint64_t iteration_offset, std::uint64_t n_generations, int blocking);
+}
 } // namespace
 
 namespace {
@@ -1725,7 +1940,9 @@ int finish_strip(Strip *st, const ststhip_domain *dom, ststhip_strip *strip) {
         return fail(STSTHIP_ERR_INVALID, "bad sweep description");
     }
     st->n_planes = d.n_planes;
-    st->g_max = std::uint64_t(d.max_generations) * d.halo_depth_per_generation;
+    // (the deepest launch the strip driver plans: the family's trusted depth, ststhip_strip_advance)
+    st->g_max = std::uint64_t(d.alt_generations && d.alt_generations < d.max_generations ? d.alt_generations : d.max_generations) *
+                d.halo_depth_per_generation;
     std::uint64_t thinnest = st->total_rows;
     for (int r = 0; r < st->n_ranks; r++) {
         std::uint64_t a, b;
@@ -1810,7 +2027,7 @@ int ststhip_strip_create(const char *app, const void *tf_params, const void *hal
     st->total_rows = total_rows;
     st->width = width;
     strip_bounds(total_rows, n_ranks, rank, st->row_begin, st->row_end);
-    ststhip_domain whole;
+    ststhip_domain whole = {};
     whole.global_height = total_rows;
     whole.global_width = width;
     whole.pitch = width;
@@ -1847,7 +2064,7 @@ int ststhip_strip_create_custom(ststhip_sweep_fn sweep, void *ctx, const ststhip
     st->resolved.trampoline = sweep;
     st->resolved.ctx = ctx;
     st->resolved.desc = *desc;
-    ststhip_domain whole;
+    ststhip_domain whole = {};
     whole.global_height = total_rows;
     whole.global_width = width;
     whole.pitch = width;
@@ -1872,6 +2089,10 @@ int ststhip_strip_destroy(ststhip_strip strip) {
         for (void *plane : set)
             if (plane)
                 ststhip_free(plane);
+    for (auto &side : st->stage)
+        for (void *buffer : side)
+            if (buffer)
+                ststhip_free(buffer);
     if (st->compute)
         (void)hipStreamDestroy(st->compute);
     if (st->comm_stream)
@@ -1934,7 +2155,7 @@ int ststhip_strip_warm_up(ststhip_strip strip) {
     if (st->n_ranks == 1)
         return STSTHIP_OK;
     HIP_TRY(hipStreamSynchronize(st->compute));
-    if (int rc = strip_exchange(*st, st->current, st->g_max))
+    if (int rc = st->is_block ? block_exchange(*st, st->current, st->g_max) : strip_exchange(*st, st->current, st->g_max))
         return rc;
     HIP_TRY(hipStreamSynchronize(st->comm_stream));
     return STSTHIP_OK;
@@ -1958,8 +2179,13 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     Strip *st = static_cast<Strip *>(strip);
     if (!st)
         return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (st->is_block)
+        return block_advance(st, iteration_offset, n_generations, blocking);
     const ststhip_sweep_desc &d = st->resolved.desc;
-    const std::vector<std::uint32_t> depths = plan_depths(n_generations, d.max_generations);
+    // (every rank must plan the same launches, so nothing is measured here: a family with a second depth runs the one
+    // its rule trusts)
+    const std::vector<std::uint32_t> depths =
+        plan_depths(n_generations, d.max_generations, d.alt_generations < d.max_generations ? d.alt_generations : 0);
     if (depths.empty())
         return STSTHIP_OK;
     st->resolved.set_run(iteration_offset, n_generations);
@@ -2093,6 +2319,368 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     if (tdv_table)
         ststhip_free_async(tdv_table, lane); // every stream has been joined into the compute stream above
     return rc; // the events go back to the pool (EventPool)
+}
+
+
+// ------------------------------------------------------------------ 2-D block driver (one block per process / GPU)
+// The minimal form of the reference's tile geometry (StencilStream/tiling/Grid.hpp:305-450: a tile with its halo from the
+// neighbouring tiles; tiling/StencilUpdate.hpp:216-247: one pass over the tiles per group of generations) on a mesh of
+// GPUs: ghost columns are strided in memory, so they travel packed; corners arrive by exchanging the columns first and
+// then the rows over the full buffer width.  No overlap of exchange and interior here (ststhip.h).
+} // extern "C"
+
+namespace {
+// rows x width rectangle between pitched buffers, in units of U (4-byte words where everything is aligned, else bytes)
+template <typename U>
+__global__ void __launch_bounds__(256) copy_rect_kernel(U *dst, std::size_t dst_pitch, const U *src, std::size_t src_pitch,
+                                                        unsigned width, unsigned rows) {
+    const std::size_t i = blockIdx.x * std::size_t(256) + threadIdx.x;
+    if (i >= std::size_t(width) * rows)
+        return;
+    const std::size_t r = i / width, c = i % width;
+    dst[r * dst_pitch + c] = src[r * src_pitch + c];
+}
+
+int copy_rect(void *dst, std::size_t dst_pitch_bytes, const void *src, std::size_t src_pitch_bytes, std::size_t width_bytes,
+              std::size_t rows, hipStream_t stream) {
+    if (width_bytes == 0 || rows == 0)
+        return STSTHIP_OK;
+    const bool words = (reinterpret_cast<std::uintptr_t>(dst) | reinterpret_cast<std::uintptr_t>(src) | dst_pitch_bytes |
+                        src_pitch_bytes | width_bytes) % 4 == 0;
+    const std::size_t unit = words ? 4 : 1;
+    const std::size_t n = width_bytes / unit * rows;
+    if (n >= (1ull << 32) || width_bytes / unit >= (1ull << 32))
+        return fail(STSTHIP_ERR_INVALID, "ghost-column block too large");
+    const unsigned blocks = unsigned((n + 255) / 256);
+    if (words)
+        hipLaunchKernelGGL(copy_rect_kernel<std::uint32_t>, dim3(blocks), dim3(256), 0, stream, static_cast<std::uint32_t *>(dst),
+                           dst_pitch_bytes / 4, static_cast<const std::uint32_t *>(src), src_pitch_bytes / 4,
+                           unsigned(width_bytes / 4), unsigned(rows));
+    else
+        hipLaunchKernelGGL(copy_rect_kernel<unsigned char>, dim3(blocks), dim3(256), 0, stream, static_cast<unsigned char *>(dst),
+                           dst_pitch_bytes, static_cast<const unsigned char *>(src), src_pitch_bytes, unsigned(width_bytes),
+                           unsigned(rows));
+    HIP_TRY(hipGetLastError());
+    return STSTHIP_OK;
+}
+
+// ghost cells of depth g around the owned block of buffer set `set`, on the comm stream: columns (packed), then rows
+int block_exchange(Strip &st, int set, std::uint64_t g) {
+    if (g == 0 || (st.mesh_rows == 1 && st.mesh_cols == 1))
+        return STSTHIP_OK;
+    const bool has_left = st.mesh_c > 0, has_right = st.mesh_c + 1 < st.mesh_cols;
+    const bool has_up = st.mesh_r > 0, has_down = st.mesh_r + 1 < st.mesh_rows;
+    const std::uint64_t owned_rows = st.row_end - st.row_begin, owned_cols = st.col_end - st.col_begin;
+    hipStream_t s = st.comm_stream;
+    st.n_exchanges++;
+    if (has_left || has_right) {
+        const void *send_left[16], *send_right[16];
+        void *recv_left[16], *recv_right[16];
+        std::size_t bytes[16];
+        for (unsigned p = 0; p < st.n_planes; p++) {
+            const std::size_t pitch = std::size_t(st.dom.pitch) * st.elem[p], width = std::size_t(g) * st.elem[p];
+            unsigned char *first_owned_row = static_cast<unsigned char *>(st.planes[set][p]) + st.ghost * pitch;
+            bytes[p] = width * owned_rows;
+            send_left[p] = st.stage[0][p];
+            send_right[p] = st.stage[1][p];
+            recv_left[p] = st.stage[2][p];
+            recv_right[p] = st.stage[3][p];
+            if (has_left)
+                if (int rc = copy_rect(st.stage[0][p], width, first_owned_row + st.ghost_cols * st.elem[p], pitch, width, owned_rows, s))
+                    return rc;
+            if (has_right)
+                if (int rc = copy_rect(st.stage[1][p], width, first_owned_row + (st.ghost_cols + owned_cols - g) * st.elem[p], pitch,
+                                       width, owned_rows, s))
+                    return rc;
+        }
+        int rc = st.comm ? ststhip_comm_exchange_columns(st.comm, int(st.n_planes), send_left, send_right, recv_left, recv_right,
+                                                          bytes, s)
+                         : st.exchange_cols(st.exchange_cols_ctx, int(st.n_planes), send_left, send_right, recv_left, recv_right,
+                                            bytes, 1, s);
+        if (rc != STSTHIP_OK)
+            return rc;
+        for (unsigned p = 0; p < st.n_planes; p++) {
+            const std::size_t pitch = std::size_t(st.dom.pitch) * st.elem[p], width = std::size_t(g) * st.elem[p];
+            unsigned char *first_owned_row = static_cast<unsigned char *>(st.planes[set][p]) + st.ghost * pitch;
+            if (has_left)
+                if (int rc2 = copy_rect(first_owned_row + (st.ghost_cols - g) * st.elem[p], pitch, st.stage[2][p], width, width, owned_rows, s))
+                    return rc2;
+            if (has_right)
+                if (int rc2 = copy_rect(first_owned_row + (st.ghost_cols + owned_cols) * st.elem[p], pitch, st.stage[3][p], width, width,
+                                        owned_rows, s))
+                    return rc2;
+        }
+    }
+    if (has_up || has_down) {
+        // whole buffer rows, ghost columns included: what the left and right neighbours have just delivered goes on to
+        // the blocks above and below -- their corners
+        const void *send_up[16], *send_down[16];
+        void *recv_up[16], *recv_down[16];
+        std::size_t row_bytes[16];
+        const std::uint64_t o_start = st.ghost, o_stop = st.ghost + owned_rows;
+        for (unsigned p = 0; p < st.n_planes; p++) {
+            row_bytes[p] = std::size_t(st.dom.pitch) * st.elem[p];
+            unsigned char *base = static_cast<unsigned char *>(st.planes[set][p]);
+            send_up[p] = base + o_start * row_bytes[p];
+            recv_up[p] = base + (o_start - g) * row_bytes[p];
+            send_down[p] = base + (o_stop - g) * row_bytes[p];
+            recv_down[p] = base + o_stop * row_bytes[p];
+        }
+        if (st.comm)
+            return ststhip_comm_exchange_rows(st.comm, int(st.n_planes), send_up, send_down, recv_up, recv_down, row_bytes,
+                                              std::size_t(g), s);
+        return st.exchange(st.exchange_ctx, int(st.n_planes), send_up, send_down, recv_up, recv_down, row_bytes, std::size_t(g), s);
+    }
+    return STSTHIP_OK;
+}
+
+int block_advance(Strip *st, std::uint64_t iteration_offset, std::uint64_t n_generations, int blocking) {
+    const ststhip_sweep_desc &d = st->resolved.desc;
+    const std::vector<std::uint32_t> depths =
+        plan_depths(n_generations, d.max_generations, d.alt_generations < d.max_generations ? d.alt_generations : 0);
+    if (depths.empty())
+        return STSTHIP_OK;
+    st->resolved.set_run(iteration_offset, n_generations);
+    const std::uint64_t hpg = d.halo_depth_per_generation;
+    const std::size_t m = std::size_t(st->exchange_every);
+    int rc = STSTHIP_OK;
+    EventPool events;
+    auto ordered = [&](hipError_t err, const char *what) {
+        if (err != hipSuccess && rc == STSTHIP_OK)
+            rc = hip_fail(err, what);
+    };
+    auto record = [&](hipStream_t on) {
+        hipEvent_t ev = events.take();
+        if (!ev)
+            ordered(hipErrorUnknown, "hipEventCreateWithFlags");
+        else
+            ordered(hipEventRecord(ev, on), "hipEventRecord");
+        return ev;
+    };
+    auto wait = [&](hipStream_t who, hipEvent_t ev) {
+        if (ev)
+            ordered(hipStreamWaitEvent(who, ev, 0), "hipStreamWaitEvent");
+    };
+    hipStream_t lane = st->compute;
+    g_launch_concurrency = 1;
+    void *tdv_table = nullptr;
+    if (d.tdv_size > 0 && d.fill_tdv) {
+        const std::size_t bytes = std::size_t(d.tdv_size) * n_generations;
+        rc = ststhip_malloc_async(&tdv_table, bytes, lane);
+        if (rc == STSTHIP_OK) {
+            std::vector<unsigned char> values(bytes);
+            d.fill_tdv(st->resolved.ctx, iteration_offset, n_generations, values.data());
+            ordered(hipMemcpyAsync(tdv_table, values.data(), bytes, hipMemcpyHostToDevice, lane), "hipMemcpyAsync");
+            ordered(hipStreamSynchronize(lane), "hipStreamSynchronize"); // `values` is pageable and goes out of scope
+            g_tdv_table = tdv_table;
+            g_tdv_first = iteration_offset;
+            g_tdv_count = n_generations;
+            g_tdv_size = d.tdv_size;
+        }
+    }
+    auto group_depth = [&](std::size_t first) {
+        std::uint64_t sum = 0;
+        for (std::size_t i = first; i < std::min(first + m, depths.size()); i++)
+            sum += depths[i] * hpg;
+        return sum;
+    };
+    const bool has_left = st->mesh_c > 0, has_right = st->mesh_c + 1 < st->mesh_cols;
+    const bool has_up = st->mesh_r > 0, has_down = st->mesh_r + 1 < st->mesh_rows;
+    const bool alone = st->mesh_rows * st->mesh_cols == 1;
+    wait(st->comm_stream, record(lane)); // everything queued so far: a previous advance, uploads, the table
+    hipEvent_t ghosts_ready = nullptr;
+    if (!alone && rc == STSTHIP_OK) {
+        rc = block_exchange(*st, st->current, group_depth(0));
+        ghosts_ready = record(st->comm_stream);
+    }
+    std::uint64_t iteration = iteration_offset;
+    for (std::size_t first = 0; first < depths.size() && rc == STSTHIP_OK; first += m) {
+        const std::size_t last = std::min(first + m, depths.size()) - 1;
+        wait(lane, ghosts_ready);
+        std::uint64_t widen = group_depth(first);
+        for (std::size_t i = first; i <= last && rc == STSTHIP_OK; i++) {
+            const std::uint32_t depth = depths[i];
+            widen -= depth * hpg; // how far beyond the owned block this launch still has to produce
+            const std::uint64_t lo = has_up ? st->row_begin - std::min(widen, st->row_begin) : st->row_begin;
+            const std::uint64_t hi = has_down ? std::min(st->row_end + widen, st->total_rows) : st->row_end;
+            const std::uint64_t clo = has_left ? st->col_begin - std::min(widen, st->col_begin) : st->col_begin;
+            const std::uint64_t chi = has_right ? std::min(st->col_end + widen, st->total_cols) : st->col_end;
+            g_col_begin = clo;
+            g_col_end = chi;
+            rc = st->resolved.trampoline(st->resolved.ctx, &st->dom, const_cast<const void *const *>(st->planes[st->current]),
+                                         st->planes[st->current ^ 1], lo, hi, iteration, depth, lane);
+            g_col_begin = g_col_end = 0;
+            st->n_launches++;
+            st->current ^= 1;
+            iteration += depth;
+        }
+        if (last + 1 < depths.size() && !alone && rc == STSTHIP_OK) {
+            wait(st->comm_stream, record(lane));
+            rc = block_exchange(*st, st->current, group_depth(last + 1));
+            ghosts_ready = record(st->comm_stream);
+        }
+    }
+    g_tdv_table = nullptr;
+    g_tdv_count = 0;
+    wait(lane, record(st->comm_stream));
+    if (rc == STSTHIP_OK && blocking) {
+        hipError_t err = hipStreamSynchronize(lane);
+        if (err != hipSuccess)
+            rc = hip_fail(err, "hipStreamSynchronize");
+    }
+    if (tdv_table)
+        ststhip_free_async(tdv_table, lane);
+    return rc;
+}
+} // namespace
+
+extern "C" {
+
+int ststhip_block_create(const char *app, const void *tf_params, const void *halo_cell, uint64_t total_rows,
+                         uint64_t total_cols, int rank, int mesh_rows, int mesh_cols, ststhip_comm comm,
+                         ststhip_exchange_fn exchange_rows, void *exchange_rows_ctx,
+                         ststhip_exchange_fn exchange_cols, void *exchange_cols_ctx, ststhip_strip *block) {
+    const AppEntry *e = find_app(app);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    if (!tf_params || !halo_cell || !block || mesh_rows < 1 || mesh_cols < 1 || rank < 0 || rank >= mesh_rows * mesh_cols ||
+        total_rows == 0 || total_cols == 0)
+        return fail(STSTHIP_ERR_INVALID, "bad block arguments");
+    if (!comm && ((mesh_rows > 1 && !exchange_rows) || (mesh_cols > 1 && !exchange_cols)))
+        return fail(STSTHIP_ERR_INVALID, "several blocks need a communicator or exchange callbacks for rows and columns");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    Strip *st = new Strip;
+    st->is_block = true;
+    st->app = app;
+    st->params.assign(static_cast<const unsigned char *>(tf_params),
+                      static_cast<const unsigned char *>(tf_params) + std::max<std::uint32_t>(e->info.params_size, 1));
+    st->halo.assign(static_cast<const unsigned char *>(halo_cell), static_cast<const unsigned char *>(halo_cell) + e->info.cell_size);
+    st->rank = rank;
+    st->n_ranks = mesh_rows * mesh_cols;
+    st->mesh_rows = mesh_rows;
+    st->mesh_cols = mesh_cols;
+    st->mesh_r = rank / mesh_cols;
+    st->mesh_c = rank % mesh_cols;
+    st->comm = static_cast<Comm *>(comm);
+    st->exchange = exchange_rows;
+    st->exchange_ctx = exchange_rows_ctx;
+    st->exchange_cols = exchange_cols;
+    st->exchange_cols_ctx = exchange_cols_ctx;
+    st->total_rows = total_rows;
+    st->total_cols = st->width = total_cols;
+    strip_bounds(total_rows, mesh_rows, st->mesh_r, st->row_begin, st->row_end);
+    strip_bounds(total_cols, mesh_cols, st->mesh_c, st->col_begin, st->col_end);
+    ststhip_domain whole = {};
+    whole.global_height = total_rows;
+    whole.global_width = total_cols;
+    whole.pitch = total_cols;
+    whole.local_rows = total_rows;
+    whole.local_cols = total_cols; // (a block: the sweeps run on cells, never on the packed words of the Game of Life)
+    const ststhip_domain *dom = &whole;
+    int rc = resolve_app(st->resolved, st->app.c_str(), st->params.data(), st->halo.data(), dom, nullptr, nullptr, false);
+    if (rc != STSTHIP_OK) {
+        delete st;
+        return rc;
+    }
+    const ststhip_sweep_desc &d = st->resolved.desc;
+    st->n_planes = d.n_planes;
+    st->g_max = std::uint64_t(d.alt_generations && d.alt_generations < d.max_generations ? d.alt_generations : d.max_generations) *
+                d.halo_depth_per_generation;
+    std::uint64_t thinnest = std::min(total_rows / mesh_rows, total_cols / mesh_cols);
+    int every = 1;
+    if (st->n_ranks > 1) {
+        every = opt().exchange_every > 0 ? std::min(opt().exchange_every, 16) : 2;
+        while (every > 1 && thinnest < 4 * st->g_max * std::uint64_t(every))
+            every--;
+    }
+    st->exchange_every = every;
+    st->ghost = st->g_max * std::uint64_t(every);
+    if (st->n_ranks > 1 && thinnest < 2 * st->ghost) {
+        delete st;
+        return fail(STSTHIP_ERR_INVALID, "blocks are thinner than two ghost depths: use a smaller mesh, a larger grid or a "
+                                         "smaller STSTHIP_EXCHANGE_EVERY");
+    }
+    // ghost columns: the exchanged depth, and a few more so that the strips next to the block's sides run the check-free
+    // code (a wave's footprint is rounded up to whole lanes); the extra columns are never exchanged and never matter
+    st->ghost_cols = (st->ghost + 8 + 3) / 4 * 4;
+    st->row_origin = std::int64_t(st->row_begin) - std::int64_t(st->ghost);
+    st->local_rows = (st->row_end - st->row_begin) + 2 * st->ghost;
+    st->col_origin = std::int64_t(st->col_begin) - std::int64_t(st->ghost_cols);
+    st->local_cols = (st->col_end - st->col_begin) + 2 * st->ghost_cols;
+    st->dom = ststhip_domain{};
+    st->dom.global_height = total_rows;
+    st->dom.global_width = total_cols;
+    st->dom.row_origin = st->row_origin;
+    st->dom.local_rows = st->local_rows;
+    st->dom.pitch = st->local_cols;
+    st->dom.col_origin = st->col_origin;
+    st->dom.local_cols = st->local_cols;
+    hipError_t err = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
+    if (err == hipSuccess)
+        err = hipStreamCreateWithFlags(&st->comm_stream, hipStreamNonBlocking);
+    for (int set = 0; set < 2 && err == hipSuccess && rc == STSTHIP_OK; set++)
+        for (unsigned p = 0; p < st->n_planes && rc == STSTHIP_OK; p++) {
+            st->elem[p] = d.plane_elem_size[p];
+            const std::size_t bytes = std::size_t(st->local_rows) * st->local_cols * st->elem[p];
+            rc = ststhip_malloc_async(&st->planes[set][p], bytes, st->compute);
+            if (rc == STSTHIP_OK)
+                err = hipMemsetAsync(st->planes[set][p], 0, bytes, st->compute);
+        }
+    if (st->mesh_cols > 1)
+        for (int side = 0; side < 4 && rc == STSTHIP_OK; side++)
+            for (unsigned p = 0; p < st->n_planes && rc == STSTHIP_OK; p++)
+                rc = ststhip_malloc_async(&st->stage[side][p], std::size_t(st->row_end - st->row_begin) * st->ghost * st->elem[p],
+                                          st->compute);
+    if (err != hipSuccess)
+        rc = hip_fail(err, "block set-up");
+    if (rc == STSTHIP_OK && (err = hipStreamSynchronize(st->compute)) != hipSuccess)
+        rc = hip_fail(err, "block set-up");
+    if (rc != STSTHIP_OK) {
+        ststhip_strip_destroy(st);
+        return rc;
+    }
+    *block = st;
+    return STSTHIP_OK;
+}
+
+int ststhip_block_geometry(ststhip_strip block, uint64_t *row_begin, uint64_t *row_end, uint64_t *col_begin,
+                           uint64_t *col_end) {
+    Strip *st = static_cast<Strip *>(block);
+    if (!st)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (row_begin)
+        *row_begin = st->row_begin;
+    if (row_end)
+        *row_end = st->row_end;
+    if (col_begin)
+        *col_begin = st->is_block ? st->col_begin : 0;
+    if (col_end)
+        *col_end = st->is_block ? st->col_end : st->width;
+    return STSTHIP_OK;
+}
+
+static int block_copy(Strip *st, unsigned plane, void *host, size_t host_pitch_bytes, bool upload) {
+    if (!st || plane >= st->n_planes || !host)
+        return fail(STSTHIP_ERR_INVALID, "bad plane index or null argument");
+    const std::size_t e = st->elem[plane], pitch = std::size_t(st->dom.pitch) * e;
+    const std::size_t ghost_cols = st->is_block ? st->ghost_cols : 0;
+    const std::size_t owned_cols = st->is_block ? st->col_end - st->col_begin : st->dom.global_width;
+    unsigned char *owned = static_cast<unsigned char *>(st->planes[st->current][plane]) + st->ghost * pitch + ghost_cols * e;
+    if (host_pitch_bytes < owned_cols * e)
+        return fail(STSTHIP_ERR_INVALID, "host pitch smaller than the block's row");
+    HIP_TRY(upload ? hipMemcpy2DAsync(owned, pitch, host, host_pitch_bytes, owned_cols * e, st->row_end - st->row_begin,
+                                      hipMemcpyHostToDevice, st->compute)
+                   : hipMemcpy2DAsync(host, host_pitch_bytes, owned, pitch, owned_cols * e, st->row_end - st->row_begin,
+                                      hipMemcpyDeviceToHost, st->compute));
+    HIP_TRY(hipStreamSynchronize(st->compute));
+    return STSTHIP_OK;
+}
+int ststhip_block_upload(ststhip_strip block, unsigned plane, const void *host_cells, size_t host_pitch_bytes) {
+    return block_copy(static_cast<Strip *>(block), plane, const_cast<void *>(host_cells), host_pitch_bytes, true);
+}
+int ststhip_block_download(ststhip_strip block, unsigned plane, void *host_cells, size_t host_pitch_bytes) {
+    return block_copy(static_cast<Strip *>(block), plane, host_cells, host_pitch_bytes, false);
 }
 
 } // extern "C"

@@ -68,7 +68,8 @@ class HipSweep:
         info = capi.app_info("jacobi5uniform" if self.uniform is not None else app)
         self.n_planes = info.n_planes
         self.plane_elem_size = [info.plane_elem_size[i] for i in range(info.n_planes)]
-        self.max_generations = info.max_generations
+        # the depth the family's rule trusts (a family may be compiled deeper: ststhip_app_info.default_generations)
+        self.max_generations = info.default_generations or info.max_generations
         self.halo_per_generation = info.halo_depth_per_generation
 
     def begin_run(self, iteration_offset, n_generations):
@@ -309,10 +310,12 @@ class _NullContext:
         return False
 
 
-def host_exchange_callback(rank, world):
+def host_exchange_callback(rank, world, first="chain", second="chain"):
     """An `exchange` callable for capi.Strip (contract of ststhip_comm_exchange_rows) that stages the ghost rows
     through host memory over the default process group (gloo): for hosts whose ranks RCCL cannot join -- several
-    processes sharing one GPU (tests/test_strip_native_gpu.py, `bench.py --debug-host-exchange`)."""
+    processes sharing one GPU (tests/test_strip_native_gpu.py, `bench.py --debug-host-exchange`).
+    first / second: the ranks on the "up" and "down" side (default: rank - 1 and rank + 1, a chain of strips; None =
+    no neighbour) -- the row and column callables of a capi.Block name their mesh neighbours here."""
     import ctypes as C
 
     import torch
@@ -327,8 +330,10 @@ def host_exchange_callback(rank, world):
         ops, landing = [], []
         for p in range(n_planes):
             n = row_bytes[p] * n_rows
-            for peer, send, recv in ((rank - 1, send_up[p], recv_up[p]), (rank + 1, send_down[p], recv_down[p])):
-                if peer < 0 or peer >= world:
+            peer_first = rank - 1 if first == "chain" else first
+            peer_second = rank + 1 if second == "chain" else second
+            for peer, send, recv in ((peer_first, send_up[p], recv_up[p]), (peer_second, send_down[p], recv_down[p])):
+                if peer is None or peer < 0 or peer >= world:
                     continue
                 out = torch.empty(n, dtype=torch.uint8)
                 capi.check(lib.ststhip_memcpy_d2h(C.c_void_p(out.data_ptr()), C.c_void_p(send), n, C.c_void_p(stream)), "d2h")

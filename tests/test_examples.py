@@ -155,6 +155,65 @@ def test_hotspot_hip_bit_exact(tmp_path, oracle, binary_name):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+# ------------------------------------------------------------------ the reference's own GPU compile mode (fused multiply-adds)
+# The reference's CMake targets give its GPU builds no -ffp-contract flag (CMakeLists.txt:46-51): a*b+c is fused there, and
+# north_star asks for "stated fp32 tolerance" for Jacobi and HotSpot, not bit-equality.  The *_hip_fma binaries are the
+# same unchanged sources compiled that way (examples/Makefile); they are held against the plain oracle with the tolerances
+# SURVEY 8(c) states: Jacobi abs <= 1e-5 after 1000 generations, HotSpot rel <= 1e-5 (the Jacobi bound is restated as
+# 2e-5 below, with the measurement that says why), and against the oracle compiled with fused multiply-adds as well.
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,coef", [("Jacobi5General", ["0.2", "0.2", "0.2", "0.2", "0.2"]),
+                                          ("Jacobi5General", ["0.2", "0.21", "0.19", "0.22", "0.18"]),
+                                          ("Jacobi9General", [f"{0.1 + 0.002 * i:.3f}" for i in range(9)])],
+                         ids=["5pt-uniform", "5pt-distinct", "9pt"])
+def test_jacobi_hip_fma_within_stated_tolerance(tmp_path, oracle, variant, coef):
+    binary = exe(f"jacobi_{variant}_hip_fma")
+    H, W, its = 600, 700, 1000
+    out_file = tmp_path / "out.bin"
+    res = run([binary, str(H), str(W), str(its), str(out_file)] + coef)
+    assert b"Walltime:" in res.stdout
+    got = np.fromfile(out_file, dtype=np.float32).reshape(H, W)
+    want = oracle.jacobi(variant, [float(c) for c in coef], oracle.jacobi_init(H, W), its, halo=0.0, n_threads=8)
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+    # SURVEY 8(c) states abs <= 1e-5 after 1000 generations on the premise that the rounding differences do not
+    # accumulate.  They do a little where the coefficients' sum rounds above one (5 x 0.2f = 1.0000000149): measured
+    # 1.32e-5 for that case on this backend AND between the oracle's own plain and fused builds on the host (the same
+    # number to the last digit), 1.5e-6 for distinct coefficients.  Stated bound: 2e-5.
+    assert err <= 2e-5, err
+    assert np.isfinite(got).all() and got.max() <= 1.0 + 1e-6 and got.min() >= 0.0
+    # ... and against the oracle built the same way (oracle/Makefile: liboracle_fma.so, gcc -mfma -ffp-contract=fast:
+    # the same source, multiply-adds fused): the GPU build fuses the same operations
+    if oracle.cpu_has_fma():
+        with oracle.use_fma_build():
+            fused = oracle.jacobi(variant, [float(c) for c in coef], oracle.jacobi_init(H, W), its, halo=0.0, n_threads=8)
+        err_fused = float(np.abs(got.astype(np.float64) - fused.astype(np.float64)).max())
+        assert err_fused <= 1e-6, err_fused
+        if variant == "Jacobi5General":
+            assert np.array_equal(got.view(np.uint32), fused.view(np.uint32)), "five-point: bit-identical to the fused oracle"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary_name", ["hotspot_hip_fma", "hotspot_aos_hip_fma"])
+def test_hotspot_hip_fma_within_stated_tolerance(tmp_path, oracle, binary_name):
+    binary = exe(binary_name)
+    n, its = 512, 1000
+    temp = np.full((n, n), 30.0, dtype=np.float32)
+    power = np.zeros((n, n), dtype=np.float32)
+    lo, hi = n // 4 - 1, 3 * n // 4
+    power[lo:hi, lo:hi] = 0.5
+    temp.tofile(tmp_path / "temp.bin")
+    power.tofile(tmp_path / "power.bin")
+    run([binary, str(n), str(n), str(its), str(tmp_path / "temp.bin"), str(tmp_path / "power.bin"),
+         str(tmp_path / "out.bin")])
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.float32).reshape(n, n)
+    cells = np.zeros((n, n), dtype=oracle.HOTSPOT_CELL)
+    cells["temp"], cells["power"] = temp, power
+    want = oracle.hotspot(oracle.hotspot_params(n, n), cells, its, n_threads=8)["temp"]
+    rel = float((np.abs(got.astype(np.float64) - want) / np.abs(want)).max())
+    assert rel <= 1e-5, rel  # rel <= 1e-5
+    assert not np.array_equal(temp, got)
+
+
 FDTD_EXPERIMENT = {
     "tau": 100e-15, "dx": 10e-9,
     "time": {"t_cutoff": 0.2, "t_detect": 0.3, "t_max": 0.5, "t_snap": 0.2},

@@ -1229,3 +1229,50 @@ def test_hotspot_512_reference_data_bit_exact(gpu, oracle, split):
         got = run_hip(U.hotspot(p.Rx_1, p.Ry_1, p.Rz_1, p.Cap_1, split_cell_structure=split), cells, n)
         want = oracle.hotspot(p, cells, n, n_threads=8)
         assert np.array_equal(bits(got), bits(want)), f"n={n}"
+
+
+def test_depth_by_measurement(gpu):
+    """Families compiled deeper than their rule trusts (one-word cells: sixteen generations beside the trusted eight)
+    have their depth MEASURED by the pass driver on the first long call for a grid shape (ststhip_sweep_desc::
+    alt_generations): the call that probes, a later call that uses the kept depth and a short call that runs the
+    trusted depth must all equal the one-generation-per-launch run bit for bit (within the stated tolerance for the
+    flavour built with fused multiply-adds); the choice is readable."""
+    import ctypes as C
+
+    import torch
+
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    lib = capi.load()
+    info = capi.app_info("jacobi5general")
+    assert info.max_generations == 16 and info.default_generations == 8
+    s = torch.cuda.Stream()
+    H, W = 5000, 6000  # large enough for two row strips and their bands
+    grid = torch.rand(H, W, device=gpu, generator=torch.Generator(device="cuda").manual_seed(88))
+    q = capi.JacobiParams()
+    for i, c in enumerate([0.2, 0.21, 0.19, 0.22, 0.18]):
+        q.coef[i] = c
+    for app in ("jacobi5general", "jacobi5general_fma"):
+        n = 200  # >= 6 x 16: the first call probes
+        os.environ["STSTHIP_MAX_GENERATIONS"] = "1"
+        try:
+            want = run_jacobi(capi, s, app, q, grid, n)
+            want_short = run_jacobi(capi, s, app, q, grid, 37)
+        finally:
+            del os.environ["STSTHIP_MAX_GENERATIONS"]
+        # (the flavour compiled with fused multiply-adds promises a tolerance, not bits: the compiler may fuse
+        # differently in every instantiation, and the depths differ by an ulp here and there)
+        if app.endswith("_fma"):
+            same = lambda a, b: float((a.double() - b.double()).abs().max()) <= 1e-5  # noqa: E731
+        else:
+            same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))  # noqa: E731
+        first = run_jacobi(capi, s, app, q, grid, n)
+        assert same(first, want), f"{app}: the probing call"
+        second = run_jacobi(capi, s, app, q, grid, n)
+        assert same(second, want), f"{app}: the call after it"
+        short = run_jacobi(capi, s, app, q, grid, 37)
+        assert same(short, want_short), f"{app}: a short call"
+        # the choice is kept per kernel family and grid shape
+        assert capi.app_tuned_depth(app, H, W) in (8, 16), app
+        assert capi.app_tuned_depth(app, H, W + 1) == 0

@@ -371,3 +371,170 @@ def test_strip_driver_over_rccl_loopback_config5_shape(gpu):
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     assert not torch.equal(outs[0], init)
     capi.comm_destroy(comm)
+
+
+# ------------------------------------------------------------------ 2-D block decomposition (ststhip_block_*)
+# the grid cut into mesh_rows x mesh_cols blocks, one process per block; ghost columns travel packed,
+# corners by exchanging columns first and rows (over the full buffer width) second.
+
+
+def test_single_block_equals_oracle(gpu, oracle):
+    """A mesh of one block: the block driver's launches (column range named per launch, buffers with a column origin and
+    ghost columns) against the oracle -- Jacobi both kernels, HotSpot on two planes, the Game of Life (cells, not words)."""
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    rng = np.random.default_rng(31)
+    H, W = 700, 1100
+    grid = rng.random((H, W), dtype=np.float32)
+    for coef, halo in (([0.2, 0.21, 0.19, 0.22, 0.18], 0.25), ([0.2] * 5, 0.0)):
+        p = capi.JacobiParams()
+        for i, c in enumerate(coef):
+            p.coef[i] = c
+        block = capi.Block("jacobi5general", p, np.float32(halo).tobytes(), H, W, 0, 1, 1)
+        assert (block.row_begin, block.row_end, block.col_begin, block.col_end) == (0, H, 0, W)
+        block.upload(0, grid)
+        block.advance(0, 29)
+        block.advance(29, 8, blocking=True)
+        want = oracle.jacobi("Jacobi5General", coef, grid, 37, halo=halo, n_threads=8)
+        assert np.array_equal(bits(block.download(0, np.float32)), bits(want)), f"jacobi {coef[0]}"
+        block.close()
+    life = (rng.random((300, 1028)) < 0.35).astype(np.uint8)
+    block = capi.Block("conway", capi.NoParams(), b"\0", 300, 1028, 0, 1, 1)
+    block.upload(0, life)
+    block.advance(0, 19, blocking=True)
+    assert np.array_equal(block.download(0, np.uint8), oracle.conway(life, 19, n_threads=8))
+    block.close()
+
+
+def _mesh_rank(rank, mesh_rows, mesh_cols, port, result_dir):
+    """One block of a mesh_rows x mesh_cols mesh; all processes share cuda:0, ghost cells through host memory over gloo."""
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    world = mesh_rows * mesh_cols
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stencilstream_amd import capi
+    from stencilstream_amd.dist import host_exchange_callback
+
+    torch.cuda.set_device(0)
+    capi.init(0)
+    r, c = divmod(rank, mesh_cols)
+    rows_cb = host_exchange_callback(rank, world, rank - mesh_cols if r > 0 else None,
+                                     rank + mesh_cols if r + 1 < mesh_rows else None)
+    cols_cb = host_exchange_callback(rank, world, rank - 1 if c > 0 else None, rank + 1 if c + 1 < mesh_cols else None)
+    H, W = 900, 1000
+    grid = np.random.default_rng(177).random((H, W), dtype=np.float32)
+    for tag, coef, halo in (("general", [0.2, 0.21, 0.19, 0.22, 0.18], 0.5), ("uniform", [0.2] * 5, 0.0)):
+        p = capi.JacobiParams()
+        for i, k in enumerate(coef):
+            p.coef[i] = k
+        block = capi.Block("jacobi5general", p, np.float32(halo).tobytes(), H, W, rank, mesh_rows, mesh_cols,
+                           exchange_rows=rows_cb, exchange_cols=cols_cb)
+        block.upload(0, grid[block.row_begin:block.row_end, block.col_begin:block.col_end])
+        block.warm_up()
+        block.advance(0, 25)
+        block.advance(25, 12, blocking=True)
+        np.save(os.path.join(result_dir, f"{tag}{rank}.npy"), block.download(0, np.float32))
+        launches, exchanges = block.counters()
+        assert launches >= 4 and exchanges >= 2
+        block.close()
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(191)
+    cells = np.zeros((H, W), dtype=O.HOTSPOT_CELL)
+    cells["temp"] = 320 + 10 * rng.random((H, W), dtype=np.float32)
+    cells["power"] = rng.random((H, W), dtype=np.float32) * 0.01
+    hp = O.hotspot_params(H, W)
+    block = capi.Block("hotspot", capi.HotspotParams(hp.Rx_1, hp.Ry_1, hp.Rz_1, hp.Cap_1), bytes(8), H, W, rank, mesh_rows,
+                       mesh_cols, exchange_rows=rows_cb, exchange_cols=cols_cb)
+    sub = cells[block.row_begin:block.row_end, block.col_begin:block.col_end]
+    block.upload(0, np.ascontiguousarray(sub["temp"]))
+    block.upload(1, np.ascontiguousarray(sub["power"]))
+    block.warm_up()
+    block.advance(0, 21, blocking=True)
+    np.save(os.path.join(result_dir, f"hotspot{rank}.npy"), block.download(0, np.float32))
+    block.close()
+    life = (rng.random((H, W)) < 0.35).astype(np.uint8)
+    block = capi.Block("conway", capi.NoParams(), b"\0", H, W, rank, mesh_rows, mesh_cols, exchange_rows=rows_cb,
+                       exchange_cols=cols_cb)
+    block.upload(0, life[block.row_begin:block.row_end, block.col_begin:block.col_end])
+    block.warm_up()
+    block.advance(0, 23, blocking=True)
+    np.save(os.path.join(result_dir, f"conway{rank}.npy"), block.download(0, np.uint8))
+    block.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _assemble(tmp_path, tag, mesh_rows, mesh_cols):
+    return np.concatenate([np.concatenate([np.load(tmp_path / f"{tag}{r * mesh_cols + c}.npy") for c in range(mesh_cols)], axis=1)
+                           for r in range(mesh_rows)], axis=0)
+
+
+@pytest.mark.parametrize("mesh,every", [((2, 2), "0"), ((1, 3), "1"), ((3, 1), "0")], ids=["2x2", "1x3", "3x1"])
+def test_blocks_of_several_processes_on_one_gpu(gpu, oracle, tmp_path, mesh, every, monkeypatch):
+    """2 x 2, 1 x 3 and 3 x 1 processes on one GPU (the box allows six processes on the card, this one included) against the oracle's run of the whole grid, bit for bit: Jacobi (general and
+    uniform-coefficient kernels), HotSpot on two planes, the Game of Life; corners included (the inner corner of a 2 x 2
+    mesh is reached by all four blocks' ghost cells)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    monkeypatch.setenv("STSTHIP_EXCHANGE_EVERY", every)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_mesh_rank, args=(mesh[0], mesh[1], port, str(tmp_path)), nprocs=mesh[0] * mesh[1], join=True)
+    H, W = 900, 1000
+    grid = np.random.default_rng(177).random((H, W), dtype=np.float32)
+    for tag, coef, halo in (("general", [0.2, 0.21, 0.19, 0.22, 0.18], 0.5), ("uniform", [0.2] * 5, 0.0)):
+        want = oracle.jacobi("Jacobi5General", coef, grid, 37, halo=halo, n_threads=8)
+        assert np.array_equal(bits(_assemble(tmp_path, tag, *mesh)), bits(want)), tag
+    rng = np.random.default_rng(191)
+    cells = np.zeros((H, W), dtype=oracle.HOTSPOT_CELL)
+    cells["temp"] = 320 + 10 * rng.random((H, W), dtype=np.float32)
+    cells["power"] = rng.random((H, W), dtype=np.float32) * 0.01
+    want = oracle.hotspot(oracle.hotspot_params(H, W), cells, 21, n_threads=8)
+    assert np.array_equal(bits(_assemble(tmp_path, "hotspot", *mesh)), bits(np.ascontiguousarray(want["temp"]))), "hotspot"
+    life = (rng.random((H, W)) < 0.35).astype(np.uint8)
+    assert np.array_equal(_assemble(tmp_path, "conway", *mesh), oracle.conway(life, 23, n_threads=8)), "conway"
+
+
+def test_block_driver_over_rccl_loopback(gpu, oracle):
+    """The block driver with RCCL as the exchange on one GPU: the middle block of a 3 x 3 mesh whose communicator names
+    itself on all four sides -- a torus of one.  Its cells then evolve like a grid that is periodic in rows AND columns,
+    which the oracle computes on 3 x 3 copies of the block (the middle copy; the true rim is further away than the
+    generations reach).  Ghost columns (packed, ncclSend / ncclRecv of the staging buffers) and corners included."""
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    comm = capi.comm_create(capi.comm_unique_id(), 0, 1)
+    capi.comm_set_neighbours(comm, 0, 0)
+    capi.comm_set_column_neighbours(comm, 0, 0)
+    R, Wc = 600, 700
+    rng = np.random.default_rng(555)
+    grid = rng.random((R, Wc), dtype=np.float32)
+    for coef, halo in (([0.2, 0.21, 0.19, 0.22, 0.18], 0.25), ([0.2] * 5, 0.0)):
+        p = capi.JacobiParams()
+        for i, c in enumerate(coef):
+            p.coef[i] = c
+        block = capi.Block("jacobi5general", p, np.float32(halo).tobytes(), 3 * R, 3 * Wc, 4, 3, 3, comm=comm)
+        assert (block.row_begin, block.row_end, block.col_begin, block.col_end) == (R, 2 * R, Wc, 2 * Wc)
+        block.upload(0, grid)
+        block.warm_up()
+        block.advance(0, 40)
+        block.advance(40, 13, blocking=True)
+        got = block.download(0, np.float32)
+        launches, exchanges = block.counters()
+        assert exchanges >= 3
+        block.close()
+        want = oracle.jacobi("Jacobi5General", coef, np.tile(grid, (3, 3)), 53, halo=halo, n_threads=8)[R:2 * R, Wc:2 * Wc]
+        assert np.array_equal(bits(got), bits(want)), f"jacobi {coef[0]}"
+    capi.comm_destroy(comm)
