@@ -596,16 +596,37 @@ struct Sweep {
     struct alignas(lane_align) LanePacket {
         std::uint32_t w[LANE_WORDS];
     };
-    STST_DEVICE static void lds_store_row(std::uint32_t *lds, int iface, int slot, int lane, Cell const (&cells)[K]) {
+    // The rings are addressed as LDS (address space 3) in the source, not through generic pointers: besides sparing
+    // the address-space inference, it keeps the optimiser from merging a store into a ring with a store into a
+    // register window at the end of two branches ("sink common code": one store through a phi of the two pointers),
+    // which made the window escape and live in scratch (HotSpot, two levels per stage: 80 bytes per lane).
+    using LdsWord = __attribute__((address_space(3))) std::uint32_t;
+    // a lane's packet moves in the widest vectors its size allows (16, 8 or 4 bytes: one ds_write_b128 / ds_read_b128 per
+    // lane and row for a 16-byte lane); builtin vector types, because a class type cannot be assigned across address spaces
+    static constexpr int CHUNK_WORDS = lane_align / 4;
+    typedef std::uint32_t LdsChunk __attribute__((ext_vector_type(CHUNK_WORDS)));
+    using LdsChunkPtr = __attribute__((address_space(3))) LdsChunk *;
+    STST_DEVICE static void lds_store_row(LdsWord *lds, int iface, int slot, int lane, Cell const (&cells)[K]) {
         LanePacket packet = {};
 #pragma unroll
         for (int k = 0; k < K; k++)
             __builtin_memcpy(&packet.w[k * CW], &cells[k], sizeof(Cell));
-        *reinterpret_cast<LanePacket *>(lds + iface * IFACE_WORDS + slot * ROW_WORDS + lane * LANE_WORDS) = packet;
+        LdsWord *at = lds + iface * IFACE_WORDS + slot * ROW_WORDS + lane * LANE_WORDS;
+#pragma unroll
+        for (int c = 0; c < LANE_WORDS / CHUNK_WORDS; c++) {
+            LdsChunk chunk;
+            __builtin_memcpy(&chunk, &packet.w[c * CHUNK_WORDS], sizeof chunk);
+            *(LdsChunkPtr)(at + c * CHUNK_WORDS) = chunk;
+        }
     }
-    STST_DEVICE static void lds_load_row(const std::uint32_t *lds, int iface, int slot, int lane, Cell (&cells)[K]) {
-        const LanePacket packet =
-            *reinterpret_cast<const LanePacket *>(lds + iface * IFACE_WORDS + slot * ROW_WORDS + lane * LANE_WORDS);
+    STST_DEVICE static void lds_load_row(const LdsWord *lds, int iface, int slot, int lane, Cell (&cells)[K]) {
+        LanePacket packet;
+        const LdsWord *at = lds + iface * IFACE_WORDS + slot * ROW_WORDS + lane * LANE_WORDS;
+#pragma unroll
+        for (int c = 0; c < LANE_WORDS / CHUNK_WORDS; c++) {
+            const LdsChunk chunk = *(const __attribute__((address_space(3))) LdsChunk *)(at + c * CHUNK_WORDS);
+            __builtin_memcpy(&packet.w[c * CHUNK_WORDS], &chunk, sizeof chunk);
+        }
 #pragma unroll
         for (int k = 0; k < K; k++)
             __builtin_memcpy(&cells[k], &packet.w[k * CW], sizeof(Cell));
@@ -618,7 +639,7 @@ struct Sweep {
     // scratch memory -- seen for large transition functions at depths of 4 and more)
     template <bool EDGE, bool SKIP_CONSTANTS, int SG>
     STST_DEVICE __attribute__((always_inline)) static void run(Args const &a, const int lane, const int strip, const int ya, const int yb,
-                                std::uint32_t *lds) {
+                                LdsWord *lds) {
         constexpr std::uint32_t skip_mask = SKIP_CONSTANTS ? constant_plane_mask<F>() : 0u;
         constexpr int L0 = SG * L; // levels below this stage
         // (read where the kernel's arguments lie: indexing the tier tables at run time must not cost a private copy)
@@ -909,7 +930,7 @@ struct Sweep {
     }
 
     template <bool SKIP_CONSTANTS = false>
-    STST_DEVICE __attribute__((always_inline)) static void entry(Args const &a, std::uint32_t *lds) {
+    STST_DEVICE __attribute__((always_inline)) static void entry(Args const &a, LdsWord *lds) {
         // (read where the kernel's arguments lie: indexing the tier tables at run time must not cost a private copy)
         SweepGeometry const &g = *(SweepGeometry const *)(const SweepGeometry __attribute__((address_space(4))) *)(
             (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(Args, geo));
@@ -985,7 +1006,7 @@ template <typename SW, int MIN_WAVES = 1, bool SKIP_CONSTANTS = false>
 __global__ void __launch_bounds__(SW::block_waves * wave_size, MIN_WAVES) sweep_kernel(const typename SW::Args args) {
     // the row rings between the stages of a staged sweep (one word otherwise)
     __shared__ __attribute__((aligned(16))) std::uint32_t rings[SW::LDS_WORDS];
-    SW::template entry<SKIP_CONSTANTS>(SW::kernel_arguments(), rings); // `args` itself is not touched (see there)
+    SW::template entry<SKIP_CONSTANTS>(SW::kernel_arguments(), (typename SW::LdsWord *)rings); // `args` itself is not touched (see there)
 }
 
 // ------------------------------------------------------------------ host side

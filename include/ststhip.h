@@ -254,6 +254,11 @@ typedef struct {
                                      tuning compiles a deeper family than it trusts: ststhip_sweep_desc::alt_generations) */
 } ststhip_app_info;
 
+/* Largest scratch (private memory: register spills, dynamically indexed locals) per work-item over the kernels a
+ * launch of `app` at depth `n_generations` may start (default shape, narrow form, constant-plane variant), from the
+ * code object.  The shipped library has none at any depth (tests/test_parity_gpu.py asserts it). */
+int ststhip_app_scratch_bytes(const char *app, uint32_t n_generations, size_t *bytes_per_work_item);
+
 int ststhip_app_count(void);
 int ststhip_app_info_at(int index, ststhip_app_info *info);
 int ststhip_app_find(const char *name, ststhip_app_info *info);

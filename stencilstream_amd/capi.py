@@ -217,6 +217,7 @@ def load():
                                C.POINTER(RunInfo)],
         "ststhip_tuned_depth": [u64, u64, u64, C.POINTER(u32)],
         "ststhip_app_tuned_depth": [C.c_char_p, u64, u64, C.POINTER(u32)],
+        "ststhip_app_scratch_bytes": [C.c_char_p, u32, C.POINTER(sz)],
         "ststhip_comm_unique_id": [C.c_char_p],
         "ststhip_comm_create": [C.c_char_p, C.c_int, C.c_int, pp],
         "ststhip_comm_destroy": [vp],
@@ -385,6 +386,13 @@ def app_run(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, iteration_offse
         f"ststhip_app_run({app})",
     )
     return info
+
+
+def app_scratch_bytes(app, n_generations):
+    """Largest scratch per work-item over the kernels a launch of `app` at this depth may start."""
+    b = C.c_size_t()
+    check(load().ststhip_app_scratch_bytes(app.encode(), int(n_generations), C.byref(b)), "ststhip_app_scratch_bytes")
+    return int(b.value)
 
 
 def app_tuned_depth(app, height, width):

@@ -21,6 +21,9 @@ struct AppEntry {
     // values of generations [iteration_offset, iteration_offset + n) into `values` (n * info.tdv_size bytes),
     // evaluated on the host; nullptr for functions without a time-dependent value
     void (*fill_tdv)(const void *tf_params, std::uint64_t iteration_offset, std::uint64_t n, void *values);
+    // largest scratch (private memory) per work-item over the kernels a launch of `n_generations` may start: the
+    // default shape, its narrow form, the variant that leaves out constant planes
+    int (*scratch_bytes)(std::uint32_t n_generations, std::size_t *bytes);
 };
 
 void register_app(AppEntry const &entry);
@@ -78,6 +81,41 @@ template <typename F, bool SOA> struct AppAdapter {
         }
     }
 
+    // scratch of every kernel dispatch_sweep<F, SOA> can reach at depth T (and of the narrow form's)
+    template <typename G, int T> static int scratch_of_depth(std::uint32_t n_generations, std::size_t &worst) {
+        namespace in = stencil::hip::internal;
+        using GT = stencil::hip::SweepTuning<G, SOA>;
+        if (n_generations == std::uint32_t(T)) {
+            auto ask = [&](const void *kernel) {
+                std::size_t b = 0;
+                const int rc = ststhip_kernel_scratch_bytes(kernel, &b);
+                worst = std::max(worst, b);
+                return rc;
+            };
+            if (int rc = ask(reinterpret_cast<const void *>(&in::sweep_kernel<in::SweepOf<G, SOA, T>, GT::min_waves_per_simd>)))
+                return rc;
+            if constexpr (SOA && in::constant_plane_mask<G>() != 0)
+                if (int rc = ask(reinterpret_cast<const void *>(&in::sweep_kernel<in::SweepOf<G, SOA, T>, GT::min_waves_per_simd, true>)))
+                    return rc;
+            return STSTHIP_OK;
+        }
+        if constexpr (T > 1)
+            return scratch_of_depth<G, T / 2>(n_generations, worst);
+        else
+            return fail(STSTHIP_ERR_INVALID, "n_generations is not a compiled temporal-blocking depth");
+    }
+    static int scratch_bytes(std::uint32_t n_generations, std::size_t *bytes) {
+        namespace in = stencil::hip::internal;
+        std::size_t worst = 0;
+        if (int rc = scratch_of_depth<F, Tuning::max_generations>(n_generations, worst))
+            return rc;
+        if constexpr (in::has_narrow_form<F, SOA>())
+            if (int rc = scratch_of_depth<in::NarrowForm<F>, Tuning::max_generations>(n_generations, worst))
+                return rc;
+        *bytes = worst;
+        return STSTHIP_OK;
+    }
+
     static AppEntry make(const char *name) {
         AppEntry e;
         std::memset(&e.info, 0, sizeof e.info);
@@ -101,6 +139,7 @@ template <typename F, bool SOA> struct AppAdapter {
         e.info.default_generations = std::uint32_t(stencil::hip::internal::default_generations_for<F, SOA>());
         e.sweep = &sweep;
         e.fill_tdv = e.info.tdv_size ? &fill_tdv : nullptr;
+        e.scratch_bytes = &scratch_bytes;
         return e;
     }
 };

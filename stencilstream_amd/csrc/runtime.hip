@@ -1199,6 +1199,17 @@ int ststhip_tuned_depth(uint64_t tune_key, uint64_t height, uint64_t width, uint
     return STSTHIP_OK;
 }
 
+int ststhip_app_scratch_bytes(const char *app, uint32_t n_generations, size_t *bytes_per_work_item) {
+    const AppEntry *e = find_app(app);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    if (!bytes_per_work_item)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    return e->scratch_bytes(n_generations, bytes_per_work_item);
+}
+
 int ststhip_app_tuned_depth(const char *app, uint64_t height, uint64_t width, uint32_t *depth) {
     const AppEntry *e = find_app(app);
     if (!e)

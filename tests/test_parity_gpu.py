@@ -1276,3 +1276,29 @@ def test_depth_by_measurement(gpu):
         # the choice is kept per kernel family and grid shape
         assert capi.app_tuned_depth(app, H, W) in (8, 16), app
         assert capi.app_tuned_depth(app, H, W + 1) == 0
+
+
+def test_no_scratch_at_any_registered_depth(gpu):
+    """No kernel of the shipped library uses scratch (private memory), at any compiled depth of any registered
+    transition function, in any of its forms (default shape, narrow form, constant-plane variant): the code object is
+    asked (ststhip_app_scratch_bytes).  Round 3's library had 64-80 bytes per lane in some shallow depths (the kernel's
+    by-value argument block copied to private memory where the optimiser could not take it apart; the device code reads
+    its arguments where they lie since)."""
+    from stencilstream_amd import capi
+
+    capi.init(0)
+    checked, offenders = 0, []
+    for name in capi.list_apps():
+        if name.startswith("x_"):
+            continue  # registered tuning experiments of an EXPERIMENTS=1 build
+        if name.startswith("selfcheck"):
+            continue  # the reference's self-checking test function: 25 comparisons per neighbour, correctness only
+        depth = capi.app_info(name).max_generations
+        while depth >= 1:
+            b = capi.app_scratch_bytes(name, depth)
+            checked += 1
+            if b:
+                offenders.append((name, depth, b))
+            depth //= 2
+    assert checked >= 100
+    assert not offenders, offenders
