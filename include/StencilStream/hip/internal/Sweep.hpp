@@ -420,6 +420,31 @@ template <typename F, bool SOA> constexpr int default_generations_for() {
         return SweepTuning<F, SOA>::max_generations;
 }
 
+// SweepTuning<F, SOA>::pinned_stores (optional member; default: cells of up to four words; staged sweeps): keep the store
+// of a finished row -- into the LDS ring, or to HBM in the last stage -- right behind the row instead of letting the
+// scheduler collect a batch's stores at its end, where their latency sits in front of the barrier.  Measured, same box, bit
+// for bit the same results (profiles/r04_micro_variants.txt): uniform Jacobi two strips +2.3 %, single launches +2.3 %,
+// 2048-row strip +5.9 %; general Jacobi +4.9 %; HotSpot +2.4 %; packed Game of Life +2.5 %; FDTD (eight words) -2.5 %.
+template <typename F, bool SOA> constexpr bool pinned_stores_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::pinned_stores; })
+        return SweepTuning<F, SOA>::pinned_stores;
+    else
+        return cell_words<typename F::Cell, SOA>() <= 4;
+}
+
+// SweepTuning<F, SOA>::scalar_function (optional member; default: transition functions of up to nine 32-bit words): the
+// function object lives in scalar registers for the whole kernel instead of being read from the kernel-argument segment
+// wherever it is used.  The compiler re-loaded a coefficient inside the row loop, and a scalar load in flight makes the
+// wait for the FIRST row from LDS a wait for all of them (scalar loads return out of order: s_waitcnt lgkmcnt(0) instead
+// of lgkmcnt(3)).  Uniform Jacobi +1.6 %, general Jacobi +1.8 %, HotSpot +0.4 %; FDTD's fourteen words -12 % (scalar
+// register pressure), hence the size limit.
+template <typename F, bool SOA> constexpr bool scalar_function_for() {
+    if constexpr (requires { SweepTuning<F, SOA>::scalar_function; })
+        return SweepTuning<F, SOA>::scalar_function;
+    else
+        return sizeof(F) % 4 == 0 && sizeof(F) <= 36 && !std::is_empty_v<F>;
+}
+
 template <typename F, bool SOA> constexpr bool trapezoid_fill_for() {
     if constexpr (requires { SweepTuning<F, SOA>::trapezoid_fill; })
         return SweepTuning<F, SOA>::trapezoid_fill;
@@ -669,8 +694,21 @@ struct Sweep {
         // ring bounds and coefficient sets) otherwise gets a private copy of itself in scratch memory in every
         // stage's code -- 550 bytes per lane at every depth, which the spill-free depth rule then refuses.
         using ConstantF = const F __attribute__((address_space(4)));
-        F const &fn = *(F const *)(ConstantF *)((const char __attribute__((address_space(4))) *)
+        F const &fn_in_arguments = *(F const *)(ConstantF *)((const char __attribute__((address_space(4))) *)
                                                     __builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(Args, f));
+        // ... unless it is small: then it is read ONCE and kept in scalar registers (passed through readfirstlane, so
+        // that the compiler cannot turn it back into loads inside the row loop: scalar_function_for)
+        constexpr bool SCALAR_F = W > 1 && scalar_function_for<F, SOA>();
+        F fn_in_registers = fn_in_arguments;
+        if constexpr (SCALAR_F) {
+            std::uint32_t words[sizeof(F) / 4];
+            __builtin_memcpy(words, &fn_in_arguments, sizeof(F));
+#pragma unroll
+            for (unsigned i = 0; i < sizeof(F) / 4; i++)
+                words[i] = std::uint32_t(__builtin_amdgcn_readfirstlane(int(words[i])));
+            __builtin_memcpy(static_cast<void *>(&fn_in_registers), words, sizeof(F));
+        }
+        F const &fn = SCALAR_F ? fn_in_registers : fn_in_arguments;
         using ConstantTDV = const TDV __attribute__((address_space(4)));
         ConstantTDV *launch_tdv = a.tdv_table ? (ConstantTDV *)(a.tdv_table)
                                               : (ConstantTDV *)(__builtin_amdgcn_kernarg_segment_ptr());
@@ -863,7 +901,11 @@ struct Sweep {
                         const std::size_t first =
                             row_offset(g, j) + std::size_t(std::int64_t(x0 - g.col_origin));
                         if (!EDGE || vec_out) {
+                            if constexpr (W > 1 && pinned_stores_for<F, SOA>())
+                                __builtin_amdgcn_sched_barrier(0);
                             a.dst.template store<K, streaming_stores_for<F, SOA>(), skip_mask>(first, cur);
+                            if constexpr (W > 1 && pinned_stores_for<F, SOA>())
+                                __builtin_amdgcn_sched_barrier(0);
                         } else {
 #pragma unroll
                             for (int k = 0; k < K; k++)
@@ -873,8 +915,13 @@ struct Sweep {
                     }
                 } else {
                     // the row this stage emits: input of the next stage, one super-step later
-                    if (!FILLING || live)
+                    if (!FILLING || live) {
+                        if constexpr (pinned_stores_for<F, SOA>())
+                            __builtin_amdgcn_sched_barrier(0);
                         lds_store_row(lds, SG, ring + u, lane, cur);
+                        if constexpr (pinned_stores_for<F, SOA>())
+                            __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
         };
 

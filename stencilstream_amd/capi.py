@@ -9,6 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libststhip.so")
+# (A/B tools only: another build of the same library, e.g. one with experiment translation units linked in)
+if os.environ.get("STSTHIP_LIBRARY"):
+    LIB_PATH = os.path.abspath(os.environ["STSTHIP_LIBRARY"])
 
 STSTHIP_OK = 0
 STATUS_NAMES = {

@@ -162,7 +162,7 @@ def main():
 
             if fill is None:
                 pa = [(torch.rand(H, 4 * W, device=dev, generator=gen) < 0.35).to(torch.uint8).view(torch.int32)]
-            elif "_grp_" in name:  # FdtdGrouped: two planes of 16-byte halves {ex, ey, hz, hz_sum} / {ca, cb, da, db}
+            elif "_grp_" in name or (meta.n_planes == 2 and meta.plane_elem_size[0] == 16):  # FdtdGrouped: two planes of 16-byte halves {ex, ey, hz, hz_sum} / {ca, cb, da, db}
                 pa = [torch.stack([field(i, fill[i]) for i in range(4 * h, 4 * h + 4)], dim=-1).contiguous() for h in range(2)]
             elif meta.n_planes == 1:
                 pa = [torch.stack([field(i, v) for i, v in enumerate(fill)], dim=-1).contiguous()]
