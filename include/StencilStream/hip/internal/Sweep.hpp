@@ -573,7 +573,20 @@ struct Sweep {
     static constexpr int NS = int(F::n_subiterations);
     static constexpr int S = T * NS;            // pipeline levels
     static constexpr int G = R * S;             // halo depth in cells (rows and columns)
-    static constexpr int GX = round_up(G, K);   // column halo rounded to whole lanes
+    // Columns a generation's dependency cone grows by per side: R per sub-iteration -- unless the function says less
+    // (`static constexpr std::size_t halo_columns_per_generation`, an extension hint like constant_fields).  FDTD's first
+    // sub-step reads its west and north neighbours only, its second the east and south ones: over a generation the cone
+    // grows by ONE cell per side, not two, so a strip of 64 one-cell lanes produces 48 columns at eight generations per
+    // launch instead of 32 -- a third fewer bytes and instructions per useful cell: 435 -> 556 Gcell-updates/s, bit for
+    // bit the same results (profiles/r04_micro_variants.txt).  A wrong hint gives wrong results; the parity tests of the
+    // functions that carry one run at full size.  (Rows keep the generic depth: the row pipeline's lag is structural.)
+    static constexpr int GC = [] {
+        if constexpr (requires { F::halo_columns_per_generation; })
+            return T * int(F::halo_columns_per_generation);
+        else
+            return G;
+    }();
+    static constexpr int GX = round_up(GC, K);  // column halo rounded to whole lanes
     static constexpr int LW = wave_size * K;    // columns a wave loads
     static constexpr int OW = LW - 2 * GX;      // columns a unit of the wave grid produces
     static constexpr int NWIN = 2 * R;          // rows each level keeps

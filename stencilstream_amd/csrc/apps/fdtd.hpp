@@ -26,6 +26,10 @@ struct Fdtd {
     using Block = ststhip_fdtd_params;
     static constexpr std::size_t stencil_radius = 1;
     static constexpr std::size_t n_subiterations = 2;
+    // sub-iteration 0 reads hz of the cell, its WEST and its NORTH neighbour (Kernel.hpp:96-101), sub-iteration 1 reads
+    // ex of the EAST and ey of the SOUTH neighbour (:103-105): over a generation the dependency cone grows by one
+    // column per side, not by radius x sub-iterations = two (hip/internal/Sweep.hpp: GC)
+    static constexpr std::size_t halo_columns_per_generation = 1;
 
     Block p;
 
@@ -102,6 +106,7 @@ struct FdtdGrouped {
     using Block = ststhip_fdtd_params;
     static constexpr std::size_t stencil_radius = 1;
     static constexpr std::size_t n_subiterations = 2;
+    static constexpr std::size_t halo_columns_per_generation = 1; // as Fdtd above: west / north, then east / south
 
     Block p;
 
