@@ -468,6 +468,25 @@ def _mesh_rank(rank, mesh_rows, mesh_cols, port, result_dir):
     block.advance(0, 23, blocking=True)
     np.save(os.path.join(result_dir, f"conway{rank}.npy"), block.download(0, np.uint8))
     block.close()
+    # FDTD on two planes of 16-byte halves: two sub-iterations, time-dependent values (one device table per call), the
+    # column halo of its real dependency cone (halo_columns_per_generation), coordinates in the transition function
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_parity_gpu import fdtd_setup
+
+    po, pc, fcells = fdtd_setup(O, H, W)
+    raw = fcells.view(np.float32).reshape(H, W, 8)
+    block = capi.Block("fdtd_coef_grouped", pc, bytes(32), H, W, rank, mesh_rows, mesh_cols, exchange_rows=rows_cb,
+                       exchange_cols=cols_cb)
+    rs, cs = slice(block.row_begin, block.row_end), slice(block.col_begin, block.col_end)
+    n_cols = block.col_end - block.col_begin
+    block.upload(0, np.ascontiguousarray(raw[rs, cs, :4]).reshape(-1, n_cols * 4))
+    block.upload(1, np.ascontiguousarray(raw[rs, cs, 4:]).reshape(-1, n_cols * 4))
+    block.warm_up()
+    block.advance(0, 30)
+    block.advance(30, 11, blocking=True)
+    fields = block.download(0, np.dtype("V16")).view(np.float32).reshape(-1, n_cols, 4)
+    np.save(os.path.join(result_dir, f"fdtd{rank}.npy"), fields)
+    block.close()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -480,8 +499,9 @@ def _assemble(tmp_path, tag, mesh_rows, mesh_cols):
 @pytest.mark.parametrize("mesh,every", [((2, 2), "0"), ((1, 3), "1"), ((3, 1), "0")], ids=["2x2", "1x3", "3x1"])
 def test_blocks_of_several_processes_on_one_gpu(gpu, oracle, tmp_path, mesh, every, monkeypatch):
     """2 x 2, 1 x 3 and 3 x 1 processes on one GPU (the box allows six processes on the card, this one included) against the oracle's run of the whole grid, bit for bit: Jacobi (general and
-    uniform-coefficient kernels), HotSpot on two planes, the Game of Life; corners included (the inner corner of a 2 x 2
-    mesh is reached by all four blocks' ghost cells)."""
+    uniform-coefficient kernels), HotSpot on two planes, the Game of Life, FDTD (two planes of 16-byte halves, sub-iterations,
+    time-dependent values over two calls); corners included (the inner corner of a 2 x 2 mesh is reached by all four
+    blocks' ghost cells)."""
     import socket
 
     import torch.multiprocessing as mp
@@ -505,6 +525,13 @@ def test_blocks_of_several_processes_on_one_gpu(gpu, oracle, tmp_path, mesh, eve
     assert np.array_equal(bits(_assemble(tmp_path, "hotspot", *mesh)), bits(np.ascontiguousarray(want["temp"]))), "hotspot"
     life = (rng.random((H, W)) < 0.35).astype(np.uint8)
     assert np.array_equal(_assemble(tmp_path, "conway", *mesh), oracle.conway(life, 23, n_threads=8)), "conway"
+    from test_parity_gpu import fdtd_setup
+
+    po, _pc, fcells = fdtd_setup(oracle, H, W)
+    want = oracle.fdtd(po, fcells, 41, n_threads=8).view(np.float32).reshape(H, W, 8)[:, :, :4]
+    got = _assemble(tmp_path, "fdtd", *mesh)
+    assert np.array_equal(bits(got), bits(np.ascontiguousarray(want))), "fdtd"
+    assert np.abs(want[:, :, 2]).max() > 0
 
 
 def test_block_driver_over_rccl_loopback(gpu, oracle):
