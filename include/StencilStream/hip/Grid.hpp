@@ -17,6 +17,7 @@
 #include <cstring>
 #include <memory>
 #include <stdexcept>
+#include <vector>
 
 namespace stencil {
 namespace hip {
@@ -35,6 +36,8 @@ template <typename Cell> class Grid {
         // written (or freed) before it has been read
         ststhip_event upload_event = nullptr;
         bool upload_pending = false;
+        // events of an upload in row blocks (start_upload_in_blocks); the last one is what wait_upload() waits for
+        std::vector<ststhip_event> block_events;
 
         explicit Storage(sycl::range<2> extent) : extent(extent) {}
         Storage(Storage const &) = delete;
@@ -43,6 +46,8 @@ template <typename Cell> class Grid {
                 ststhip_event_synchronize(upload_event);
             if (upload_event)
                 ststhip_event_destroy(upload_event);
+            for (ststhip_event ev : block_events)
+                ststhip_event_destroy(ev);
             if (host)
                 ststhip_host_free(host);
             if (device)
@@ -95,6 +100,63 @@ template <typename Cell> class Grid {
                 upload_pending = true;
                 host_valid = true;
             }
+            device_valid = true;
+        }
+        // The same in row blocks, first rows first, on the runtime's upload streams: `blocks` names them for the pass
+        // driver (ststhip_set_source_arrival), which starts on the rows that have arrived instead of idling for the
+        // whole transfer (1 GiB: 18.7 ms over PCIe).  `after_block(work_stream, first_row, end_row)` may queue a
+        // kernel per block in front of its event (the scatter into per-field planes; on a stream of its own, behind
+        // the block's copy: on the copies' stream it would hold up the next transfer); `has_work` says whether it does.
+        // Nothing to upload, or a grid the rule does not split: `blocks` stays empty and the call is start_upload(s).
+        template <typename AfterBlock>
+        void start_upload_in_blocks(ststhip_stream s, std::vector<ststhip_source_block> &blocks, bool has_work,
+                                    AfterBlock &&after_block) {
+            blocks.clear();
+            std::uint32_t n_blocks = 1;
+            if (!device_valid)
+                internal::check(ststhip_suggest_upload_blocks(extent[0], extent[1] * sizeof(Cell), &n_blocks), "grid upload");
+            if (n_blocks < 2) {
+                start_upload(s);
+                return;
+            }
+            need_device();
+            need_host();
+            ststhip_stream up = nullptr, work = nullptr;
+            internal::check(ststhip_upload_streams(&up, &work), "grid upload");
+            if (!upload_event)
+                internal::check(ststhip_event_create(&upload_event), "grid upload");
+            // What `s` has queued so far comes first (buffers from the pool may still be in use by work queued there).
+            // The HOST waits for it -- `s` is idle when a grid is uploaded, as a rule --, not the copies' stream: the
+            // first copy of a process that is queued behind another stream's event costs a hipMemcpyAsync that does not
+            // return for 7.6 ms, with the chip idle behind it (tools/microbench/upload_stall.hip, variants 8 / 9).
+            internal::check(ststhip_event_record(upload_event, s), "grid upload");
+            internal::check(ststhip_event_synchronize(upload_event), "grid upload");
+            while (block_events.size() < 2 * std::size_t(n_blocks)) {
+                ststhip_event ev = nullptr;
+                internal::check(ststhip_event_create(&ev), "grid upload");
+                block_events.push_back(ev);
+            }
+            const std::size_t rows = extent[0], row_bytes = extent[1] * sizeof(Cell);
+            for (std::uint32_t b = 0; b < n_blocks; b++) {
+                const std::size_t first = rows * b / n_blocks, end = rows * (b + 1) / n_blocks;
+                internal::check(ststhip_memcpy_h2d(static_cast<char *>(device) + first * row_bytes,
+                                                   reinterpret_cast<char const *>(host) + first * row_bytes,
+                                                   (end - first) * row_bytes, up),
+                                "grid upload");
+                ststhip_event copied = block_events[2 * b], ready = copied;
+                internal::check(ststhip_event_record(copied, up), "grid upload");
+                if (has_work) {
+                    ready = block_events[2 * b + 1];
+                    internal::check(ststhip_stream_wait_event(work, copied), "grid upload");
+                    after_block(work, first, end);
+                    internal::check(ststhip_event_record(ready, work), "grid upload");
+                }
+                blocks.push_back(ststhip_source_block{end, ready});
+            }
+            // (what wait_upload() waits for: the pinned mirror has been read)
+            internal::check(ststhip_event_record(upload_event, up), "grid upload");
+            upload_pending = true;
+            host_valid = true;
             device_valid = true;
         }
         // ... and for any stream, and the pinned mirror may be rewritten by the host right after this call
@@ -169,6 +231,20 @@ template <typename Cell> class Grid {
     // The same for work queued on `stream` after this call: the upload is queued there and not waited for.
     Cell const *device_cells_on(ststhip_stream stream) {
         storage->start_upload(stream);
+        return static_cast<Cell const *>(storage->device);
+    }
+    // Where the AoS cells lie in HBM, whatever they hold (for work that is ordered against an upload by other means).
+    Cell const *device_cells_base() {
+        storage->need_device();
+        return static_cast<Cell const *>(storage->device);
+    }
+    // The same with the upload in row blocks the pass driver can follow (Storage::start_upload_in_blocks): `blocks` is
+    // what to hand to ststhip_set_source_arrival right before the update's ststhip_run_passes -- empty when there is
+    // nothing to follow, and then everything is ordered on `stream` as with device_cells_on.
+    template <typename AfterBlock>
+    Cell const *device_cells_arriving(ststhip_stream stream, std::vector<ststhip_source_block> &blocks, bool has_work,
+                                      AfterBlock &&after_block) {
+        storage->start_upload_in_blocks(stream, blocks, has_work, after_block);
         return static_cast<Cell const *>(storage->device);
     }
     // AoS cells in HBM about to be overwritten completely by a kernel on the runtime's stream.

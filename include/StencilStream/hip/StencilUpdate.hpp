@@ -91,7 +91,18 @@ class StencilUpdate {
     };
 
     StencilUpdate(Params params)
-        : params(params), n_processed_cells(0), walltime(0.0), kernel_runtime(0.0) {}
+        : params(params), n_processed_cells(0), walltime(0.0), kernel_runtime(0.0) {
+        // Building the update object loads its kernels: the code object of this instantiation is read into the device
+        // at the first question asked of one of its kernels (8 ms for the Jacobi example's) -- here, once, instead of
+        // inside the first call, where it used to hide behind the grid's upload and would now sit in front of the
+        // passes that follow the upload block by block (simulate()).  A host without a usable GPU learns so from
+        // operator(), as before.
+        try {
+            internal::ensure_runtime(params.device.hip_index());
+            (void)spill_free_depth();
+        } catch (...) {
+        }
+    }
 
     Params &get_params() { return params; }
     std::size_t get_n_processed_cells() const { return n_processed_cells; }
@@ -222,7 +233,7 @@ class StencilUpdate {
 
     // All passes of one call, from `source` planes into `target` planes.
     void run_passes(ststhip_domain const &dom, Planes const &source, Planes const &target,
-                    ststhip_stream stream) {
+                    ststhip_stream stream, std::vector<ststhip_source_block> const &arriving = {}) {
         ststhip_sweep_desc desc = sweep_description();
         // one device table of time-dependent values per call: filled by the host, or by the device
         void *device_values = nullptr;
@@ -245,6 +256,8 @@ class StencilUpdate {
             }
         }
         ststhip_run_info info = {};
+        // (the source's row blocks, for this call: ststhip.h, ststhip_set_source_arrival)
+        internal::check(ststhip_set_source_arrival(arriving.data(), std::uint32_t(arriving.size())), "ststhip_set_source_arrival");
         internal::check(ststhip_run_passes(&sweep_trampoline, this, &desc, &dom,
                                            const_cast<const void *const *>(source.plane), target.plane,
                                            params.iteration_offset, params.n_iterations, 0,
@@ -253,6 +266,22 @@ class StencilUpdate {
         kernel_runtime += info.kernel_time_s;
         if (device_values)
             ststhip_free_async(device_values, stream);
+    }
+
+    // The pass driver takes its swap planes from the runtime's pool when it starts.  With the upload in row blocks the
+    // chip is busy by then, and an allocation the pool has to pass on to the device waits for it (hipMalloc beside
+    // running kernels: 15 ms for 512 MiB, measured in front of the HotSpot example's first pass).  So: the planes go
+    // through the pool once BEFORE the upload is queued -- allocated and released on `stream`, where the driver's
+    // request finds them.
+    void reserve_swap_planes(ststhip_domain const &dom, ststhip_stream stream) {
+        if (params.n_iterations < 2)
+            return;
+        const std::size_t n_cells = std::size_t(dom.local_rows) * dom.pitch;
+        void *held[Planes::n_planes];
+        for (int f = 0; f < Planes::n_planes; f++)
+            held[f] = internal::device_alloc_on(n_cells * Planes::elem_size(f), stream);
+        for (int f = 0; f < Planes::n_planes; f++)
+            ststhip_free_async(held[f], stream);
     }
 
     GridImpl simulate(GridImpl &source_grid, ststhip_stream stream)
@@ -267,9 +296,13 @@ class StencilUpdate {
         Planes from, to;
         // (the upload is queued in front of the sweeps and not waited for: the result grid and the pass driver's swap
         // buffer are allocated while it runs)
-        from.plane[0] = const_cast<Cell *>(source_grid.device_cells_on(stream));
+        // ... in row blocks when it is worth it, and the pass driver starts on the rows that have arrived)
+        std::vector<ststhip_source_block> arriving;
         to.plane[0] = result.device_cells_for_overwrite();
-        run_passes(dom, from, to, stream);
+        reserve_swap_planes(dom, stream);
+        from.plane[0] = const_cast<Cell *>(
+            source_grid.device_cells_arriving(stream, arriving, false, [](ststhip_stream, std::size_t, std::size_t) {}));
+        run_passes(dom, from, to, stream, arriving);
         return result;
     }
 
@@ -284,19 +317,33 @@ class StencilUpdate {
             offsets[f] = Planes::elem_offset(f);
             sizes[f] = Planes::elem_size(f);
         }
-        // (queued first and not waited for: the planes are allocated while the cells are on their way)
-        Cell const *cells = source_grid.device_cells_on(stream);
         Planes sets[2];
         for (auto &set : sets)
             for (int f = 0; f < n; f++)
                 set.plane[f] = internal::device_alloc_on(n_cells * sizes[f], stream);
-
-        internal::check(ststhip_scatter_fields(cells, sizeof(Cell), n_cells, n,
-                                               offsets, sizes, sets[0].plane, stream),
-                        "scatter");
-        run_passes(dom, sets[0], sets[1], stream); // n_iterations == 0 copies the planes
+        // (the result's cells too, while the chip is idle: see reserve_swap_planes)
         GridImpl result = source_grid.make_similar();
-        internal::check(ststhip_gather_fields(result.device_cells_for_overwrite(), sizeof(Cell),
+        Cell *result_cells = result.device_cells_for_overwrite();
+        // The cells come up in row blocks when the grid is not in HBM yet and large enough, each block scattered into
+        // the planes behind its copy, and the pass driver follows the blocks; else one scatter on `stream`.
+        const std::size_t width = source_grid.get_grid_width();
+        Cell const *cells_base = nullptr; // (known only once the grid has its device buffer)
+        std::vector<ststhip_source_block> arriving;
+        auto scatter_rows = [&](ststhip_stream on, std::size_t first_row, std::size_t end_row) {
+            void *rows_of[n];
+            for (int f = 0; f < n; f++)
+                rows_of[f] = static_cast<char *>(sets[0].plane[f]) + first_row * width * sizes[f];
+            internal::check(ststhip_scatter_fields(cells_base + first_row * width, sizeof(Cell),
+                                                   (end_row - first_row) * width, n, offsets, sizes, rows_of, on),
+                            "scatter");
+        };
+        cells_base = source_grid.device_cells_base();
+        reserve_swap_planes(dom, stream);
+        source_grid.device_cells_arriving(stream, arriving, true, scatter_rows);
+        if (arriving.empty())
+            scatter_rows(stream, 0, source_grid.get_grid_height());
+        run_passes(dom, sets[0], sets[1], stream, arriving); // n_iterations == 0 copies the planes
+        internal::check(ststhip_gather_fields(result_cells, sizeof(Cell),
                                               n_cells, n, offsets, sizes,
                                               const_cast<const void *const *>(sets[1].plane), stream),
                         "gather");

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define STSTHIP_ABI_VERSION 5
+#define STSTHIP_ABI_VERSION 6
 
 typedef enum {
     STSTHIP_OK = 0,
@@ -177,8 +177,11 @@ typedef struct {
                                       1 (default) = time both on the first long call for a grid shape and keep the faster;
                                       0 = always the trusted depth; N >= 2 = depth N outright                         */
     int32_t exchange_every;        /* strip driver: exchange m*g ghost rows every m-th launch; 0/1 = every launch */
-    int32_t reserved1;
-    int32_t reserved[6];
+    int32_t stream_upload;         /* 1 (default) = a grid that is not in HBM yet is uploaded in row blocks and the pass
+                                      driver starts on the blocks that have arrived (ststhip_set_source_arrival); 0 = one
+                                      copy in front of the first pass                                                   */
+    int32_t upload_block_mib;      /* size of those blocks; 0 = the rule of ststhip_suggest_upload_blocks              */
+    int32_t reserved[5];
 } ststhip_options;
 const ststhip_options *ststhip_get_options(void);
 int ststhip_reload_options(void);
@@ -282,6 +285,8 @@ typedef struct {
     double kernel_time_s;     /* sum of sweep-kernel durations from HIP events (if profiling)  */
     uint64_t n_launches;      /* sweep kernels launched                                         */
     uint64_t n_processed_cells; /* n_iterations * H * W (sub-iterations not counted)           */
+    uint64_t n_streamed_passes; /* ABI 6: passes that ran as row tiles behind a source still arriving
+                                   (ststhip_set_source_arrival); 0 otherwise                              */
 } ststhip_run_info;
 
 /* cuda::StencilUpdate::operator() for a precompiled transition function: advance the whole
@@ -340,6 +345,34 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                        const ststhip_domain *dom, const void *const *src, void *const *dst,
                        uint64_t iteration_offset, uint64_t n_iterations, int blocking, int profiling,
                        ststhip_stream stream, ststhip_run_info *info);
+/* A source that is still on its way (ABI 6).  A grid's first update pays for its upload: 1 GiB takes 18.7 ms over PCIe,
+ * a quarter of a 1000-generation run of the Jacobi example, and in front of the first pass the chip idles for all of
+ * it.  A host that uploads in ROW BLOCKS (in order, first rows first) names them here for the calling thread's NEXT
+ * ststhip_run_passes / ststhip_app_run call: rows [blocks[i-1].row_end, blocks[i].row_end) of every source plane are in
+ * HBM once event blocks[i].ready has completed (the last row_end >= the grid's height; the call consumes the list
+ * whatever it returns).  The driver then starts on what has arrived: it runs its first passes as row tiles skewed in
+ * time -- pass p of the rows above block boundary b reaches g*(p+1) rows less far down than the boundary, g = ghost
+ * rows of one launch, so that every tile depends only on tiles of rows that arrived earlier --, as many passes deep
+ * as it takes to keep the chip busy between two arrivals (measured per call: the first tile column is timed against
+ * the gap between the arrival events), completes those passes over the whole grid when the last block is there and
+ * continues with whole-grid passes.  The targets alternate exactly as without the list, the result is the same bit for
+ * bit.  The host thread waits for the arrival events inside the call (also with blocking = 0).  `stream` must NOT be
+ * made to wait for the upload by the caller; when the driver cannot use the list (profiling runs, grids of few rows per
+ * block, options.stream_upload = 0) it makes `stream` wait for every block itself. */
+typedef struct {
+    uint64_t row_end;
+    ststhip_event ready;
+} ststhip_source_block;
+int ststhip_set_source_arrival(const ststhip_source_block *blocks, uint32_t n_blocks);
+/* The rule for such an upload: into how many row blocks (1 = do not split) a host should divide `rows` rows of
+ * `row_bytes` bytes (all planes together), and the streams the runtime keeps for it: `copies` for the transfers
+ * (ordered against nothing else) and `work` for kernels a host runs per block behind its copy (the scatter into
+ * per-field planes; an event per block carries the order: a kernel queued on the copies' own stream holds up the next
+ * transfer until it has found room on the chip).  Both are streams of the pass driver that idle while a source
+ * arrives -- its tiles run on the caller's stream and the driver's side stream. */
+int ststhip_suggest_upload_blocks(uint64_t rows, uint64_t row_bytes, uint32_t *n_blocks);
+int ststhip_upload_streams(ststhip_stream *copies, ststhip_stream *work);
+
 /* The depth the pass driver has measured to be the faster one for (tune_key, height, width) in this process; 0 = not
  * measured yet. */
 int ststhip_tuned_depth(uint64_t tune_key, uint64_t height, uint64_t width, uint32_t *depth);

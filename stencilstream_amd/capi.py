@@ -76,7 +76,14 @@ class RunInfo(C.Structure):
         ("kernel_time_s", C.c_double),
         ("n_launches", C.c_uint64),
         ("n_processed_cells", C.c_uint64),
+        ("n_streamed_passes", C.c_uint64),
     ]
+
+
+class SourceBlock(C.Structure):
+    """ststhip_source_block: rows up to `row_end` of a source that is arriving are in HBM once `ready` has completed"""
+
+    _fields_ = [("row_end", C.c_uint64), ("ready", C.c_void_p)]
 
 
 class JacobiParams(C.Structure):
@@ -139,8 +146,9 @@ class Options(C.Structure):
                    "max_generations", "allow_spilling_depths", "virtual_strips", "two_strips_permille",
                    "two_strips_permille_outer", "strip_skew_permille", "bands_beside_interior", "band_stream_priority",
                    "bands_apart", "bands_one_launch", "comm_stream_priority", "jacobi_fastpath", "conway_fastpath",
-                   "prepare_streams", "host_cache_mib", "tune_depth", "exchange_every", "reserved1")] + \
-               [("reserved", C.c_int32 * 6)]
+                   "prepare_streams", "host_cache_mib", "tune_depth", "exchange_every", "stream_upload",
+                   "upload_block_mib")] + \
+               [("reserved", C.c_int32 * 5)]
 
 
 _lib = None
@@ -218,6 +226,9 @@ def load():
                             vp, C.POINTER(RunInfo)],
         "ststhip_run_passes": [vp, vp, vp, C.POINTER(Domain), pp, pp, u64, u64, C.c_int, C.c_int, vp,
                                C.POINTER(RunInfo)],
+        "ststhip_set_source_arrival": [C.POINTER(SourceBlock), u32],
+        "ststhip_suggest_upload_blocks": [u64, u64, C.POINTER(u32)],
+        "ststhip_upload_streams": [pp, pp],
         "ststhip_tuned_depth": [u64, u64, u64, C.POINTER(u32)],
         "ststhip_app_tuned_depth": [C.c_char_p, u64, u64, C.POINTER(u32)],
         "ststhip_app_scratch_bytes": [C.c_char_p, u32, C.POINTER(sz)],
@@ -389,6 +400,51 @@ def app_run(app, tf_params, halo_bytes, dom, src_ptrs, dst_ptrs, iteration_offse
         f"ststhip_app_run({app})",
     )
     return info
+
+
+def suggest_upload_blocks(rows, row_bytes):
+    """Into how many row blocks a host should split the upload of `rows` rows of `row_bytes` bytes (1 = do not)."""
+    n = C.c_uint32()
+    check(load().ststhip_suggest_upload_blocks(int(rows), int(row_bytes), C.byref(n)), "ststhip_suggest_upload_blocks")
+    return int(n.value)
+
+
+def upload_stream():
+    """The stream the runtime keeps for the copies of uploads in row blocks."""
+    copies, work = C.c_void_p(), C.c_void_p()
+    check(load().ststhip_upload_streams(C.byref(copies), C.byref(work)), "ststhip_upload_streams")
+    return copies.value
+
+
+def upload_in_blocks(planes, rows, n_blocks=None):
+    """Copy `rows` rows of every plane -- `planes` = [(pinned host address, device address, bytes per row), ...] -- to
+    the device in row blocks on the runtime's upload stream, and name the blocks for the calling thread's next
+    `app_run` (ststhip_set_source_arrival).  Returns the events (`events_destroy` them after that call)."""
+    lib = load()
+    if n_blocks is None:
+        n_blocks = suggest_upload_blocks(rows, sum(row_bytes for _, _, row_bytes in planes))
+    up = upload_stream()
+    blocks = (SourceBlock * n_blocks)()
+    events = []
+    for b in range(n_blocks):
+        first, end = rows * b // n_blocks, rows * (b + 1) // n_blocks
+        for host_ptr, device_ptr, row_bytes in planes:
+            check(lib.ststhip_memcpy_h2d(C.c_void_p(device_ptr + first * row_bytes),
+                                         C.c_void_p(host_ptr + first * row_bytes), (end - first) * row_bytes,
+                                         C.c_void_p(up)), "ststhip_memcpy_h2d")
+        ev = C.c_void_p()
+        check(lib.ststhip_event_create(C.byref(ev)), "ststhip_event_create")
+        check(lib.ststhip_event_record(ev, C.c_void_p(up)), "ststhip_event_record")
+        events.append(ev)
+        blocks[b].row_end = end
+        blocks[b].ready = ev.value
+    check(lib.ststhip_set_source_arrival(blocks, n_blocks), "ststhip_set_source_arrival")
+    return events
+
+
+def events_destroy(events):
+    for ev in events:
+        check(load().ststhip_event_destroy(ev), "ststhip_event_destroy")
 
 
 def app_scratch_bytes(app, n_generations):

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -82,6 +83,8 @@ static ststhip_options read_options() {
     o.host_cache_mib = env_int("STSTHIP_HOST_CACHE_MIB", 4096);
     o.exchange_every = env_int("STSTHIP_EXCHANGE_EVERY", 0);
     o.tune_depth = env_int("STSTHIP_TUNE_DEPTH", 1);
+    o.stream_upload = env_int("STSTHIP_STREAM_UPLOAD", 1);
+    o.upload_block_mib = env_int("STSTHIP_UPLOAD_BLOCK_MIB", 0);
     return o;
 }
 static ststhip_options &options_storage() {
@@ -1154,6 +1157,68 @@ int ststhip_app_sweep(const char *app, const void *tf_params, const void *halo_c
                     n_generations, resolve(stream));
 }
 
+// ------------------------------------------------------------------ a source that is still arriving
+// (ststhip.h, ststhip_set_source_arrival; consumed by the next pass-driver call of the thread)
+extern "C++" {
+namespace {
+std::vector<ststhip_source_block> &source_arrival() {
+    static thread_local std::vector<ststhip_source_block> blocks;
+    return blocks;
+}
+} // namespace
+} // extern "C++"
+
+int ststhip_set_source_arrival(const ststhip_source_block *blocks, uint32_t n_blocks) {
+    source_arrival().clear();
+    if (n_blocks == 0)
+        return STSTHIP_OK;
+    if (!blocks)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    std::uint64_t before = 0;
+    for (std::uint32_t i = 0; i < n_blocks; i++) {
+        if (!blocks[i].ready || blocks[i].row_end <= before)
+            return fail(STSTHIP_ERR_INVALID, "source blocks need an event each and ascending row ends");
+        before = blocks[i].row_end;
+    }
+    source_arrival().assign(blocks, blocks + n_blocks);
+    return STSTHIP_OK;
+}
+
+int ststhip_suggest_upload_blocks(uint64_t rows, uint64_t row_bytes, uint32_t *n_blocks) {
+    if (!n_blocks)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    *n_blocks = 1;
+    if (!opt().stream_upload || rows == 0 || row_bytes == 0)
+        return STSTHIP_OK;
+    // Up to eight blocks of 128 MiB or more (2.3 ms over PCIe) and 256 rows or more: the first block is what the chip
+    // waits for with nothing to do; the number of blocks is how thin the tiles of the skewed passes get, and a tile
+    // of fewer cells than that leaves most of the chip idle (HotSpot 8192^2 in eight blocks of 64 MiB: 7 % SLOWER than one
+    // copy in front of the first pass, profiles/r04_stream_upload.txt).
+    const std::uint64_t bytes = rows * row_bytes;
+    const std::uint64_t block_bytes = opt().upload_block_mib > 0 ? (std::uint64_t(opt().upload_block_mib) << 20) : 0;
+    std::uint64_t n = block_bytes ? (bytes + block_bytes - 1) / block_bytes : std::min<std::uint64_t>(8, bytes >> 27);
+    n = std::min<std::uint64_t>(n, rows / 256);
+    n = std::min<std::uint64_t>(n, 64);
+    *n_blocks = std::uint32_t(std::max<std::uint64_t>(n, 1));
+    return STSTHIP_OK;
+}
+
+int ststhip_upload_streams(ststhip_stream *copies, ststhip_stream *work) {
+    if (!copies || !work)
+        return fail(STSTHIP_ERR_INVALID, "null argument");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    // the two band streams: they idle while a source arrives (the tiles of the skewed passes run on the caller's
+    // stream and the side stream), and streams of their own would be dealt onto the hardware queues of those (see
+    // shared_side_streams)
+    std::vector<hipStream_t> band;
+    if (!band_streams_for(nullptr, 2, band))
+        return fail(STSTHIP_ERR_HIP, "could not create the upload streams");
+    *copies = static_cast<ststhip_stream>(band[1]);
+    *work = static_cast<ststhip_stream>(band[0]);
+    return STSTHIP_OK;
+}
+
 // ------------------------------------------------------------------ pass driver
 // Side streams for "virtual strips": one launch per pass has a ramp-up and a ragged tail during which
 // part of the chip idles (at 16384^2 a pass is only ~3 residency rounds long).  Splitting the rows
@@ -1221,6 +1286,9 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                        const ststhip_domain *dom, const void *const *src, void *const *dst,
                        uint64_t iteration_offset, uint64_t n_iterations, int blocking, int profiling,
                        ststhip_stream stream, ststhip_run_info *info) {
+    // (the list of a source that is still arriving is for this call, whatever becomes of it)
+    std::vector<ststhip_source_block> arrival;
+    arrival.swap(source_arrival());
     if (!sweep || !desc || !dom || !src || !dst)
         return fail(STSTHIP_ERR_INVALID, "null argument");
     if (desc->n_planes < 1 || desc->n_planes > 16 || desc->max_generations < 1)
@@ -1261,26 +1329,58 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
     // of its passes is split into two of half its depth.
     const std::size_t probe_passes = probing ? 3 + 2 * (deep / alt) : 0;
     std::vector<std::uint32_t> rest_alt;
-    if (probing) {
-        for (int i = 0; i < 3; i++)
-            depths.push_back(deep);
-        for (std::uint32_t i = 0; i < 2 * (deep / alt); i++)
-            depths.push_back(alt);
-        const std::uint64_t left = n_iterations - 5ull * deep;
-        const std::vector<std::uint32_t> rest_deep = plan_depths(left, deep);
-        rest_alt = plan_depths(left, deep, alt);
-        if ((rest_alt.size() + rest_deep.size()) % 2 != 0) {
-            // split the first pass of depth `alt` (there is one: left >= deep) into two of alt / 2
-            for (std::size_t i = 0; i < rest_alt.size(); i++)
-                if (rest_alt[i] == alt) {
-                    rest_alt[i] = alt / 2;
-                    rest_alt.insert(rest_alt.begin() + i, alt / 2);
-                    break;
-                }
+    // (a lambda: planned again for what is left once the passes behind an arriving source have run)
+    auto plan = [&](std::uint64_t n) {
+        depths.clear();
+        rest_alt.clear();
+        if (probing) {
+            for (int i = 0; i < 3; i++)
+                depths.push_back(deep);
+            for (std::uint32_t i = 0; i < 2 * (deep / alt); i++)
+                depths.push_back(alt);
+            const std::uint64_t left = n - 5ull * deep;
+            const std::vector<std::uint32_t> rest_deep = plan_depths(left, deep);
+            rest_alt = plan_depths(left, deep, alt);
+            if ((rest_alt.size() + rest_deep.size()) % 2 != 0) {
+                // split the first pass of depth `alt` (there is one: left >= deep) into two of alt / 2
+                for (std::size_t i = 0; i < rest_alt.size(); i++)
+                    if (rest_alt[i] == alt) {
+                        rest_alt[i] = alt / 2;
+                        rest_alt.insert(rest_alt.begin() + i, alt / 2);
+                        break;
+                    }
+            }
+            depths.insert(depths.end(), rest_deep.begin(), rest_deep.end()); // replaced by rest_alt if alt wins
+        } else {
+            depths = plan_depths(n, deep, depth_cap);
         }
-        depths.insert(depths.end(), rest_deep.begin(), rest_deep.end()); // replaced by rest_alt if alt wins
-    } else {
-        depths = plan_depths(n_iterations, deep, depth_cap);
+    };
+    plan(n_iterations);
+    // The passes the whole call takes; which of `dst` and the scratch planes a pass writes follows from its index and
+    // this number alone (the last one writes `dst`).
+    const std::size_t total_passes = depths.size();
+
+    // A source that is still arriving (ststhip_set_source_arrival): the first `streamed` passes run as row tiles
+    // behind it, at the depth the plan starts with.  How many is decided while they run, so the plan of the rest
+    // must have the same length for every choice: it has when the choice is a multiple of `quantum` (a plan is
+    // greedy: whole launches of its depth first; in a probing call 2 * deep / alt of them make two launches of `deep`).
+    const std::uint32_t tile_depth = depths.empty() ? 0 : (probing ? alt : depths.front());
+    const std::uint64_t tile_g = std::uint64_t(tile_depth) * desc->halo_depth_per_generation;
+    const std::uint32_t quantum = probing ? 2 * (deep / alt) : 1;
+    std::uint64_t stream_limit = 0; // passes that may run behind the source, at most
+    if (arrival.size() >= 2 && !profiling && opt().stream_upload && tile_depth > 0) {
+        std::uint64_t thinnest = ~0ull, before = 0;
+        for (auto const &blk : arrival) {
+            thinnest = std::min(thinnest, std::min(blk.row_end, H) - std::min(before, H));
+            before = blk.row_end;
+        }
+        // pass p of a block's column ends (p + 1) * g rows above the block's end: inside the block for every p
+        const std::uint64_t by_rows = thinnest > tile_g ? (thinnest - 1) / tile_g - 1 : 0;
+        const std::uint64_t spare = probing ? n_iterations - 6ull * deep : n_iterations;
+        stream_limit = std::min(by_rows, spare / tile_depth);
+        stream_limit -= stream_limit % quantum;
+        if (before < H || stream_limit < 2)
+            stream_limit = 0;
     }
     hipEvent_t probe_events[3] = {nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
@@ -1300,6 +1400,12 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                                 desc->halo_depth_per_generation;
     int strips = profiling ? 1
                            : suggest_row_strips(H, dom->global_width, desc->strip_width, g_max, depths.size());
+
+    // a source in blocks that this call does not follow block by block: everything waits for all of it
+    if (stream_limit == 0)
+        for (auto const &blk : arrival)
+            ordered(hipStreamWaitEvent(s, static_cast<hipEvent_t>(blk.ready), 0), "hipStreamWaitEvent");
+    std::uint64_t streamed = 0; // passes that ran behind the arriving source
 
     if (depths.empty()) {
         for (unsigned p = 0; p < n_planes && rc == STSTHIP_OK; p++)
@@ -1335,6 +1441,159 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                 ordered(hipErrorUnknown, "hipEventCreateWithFlags");
             return e;
         };
+        // which planes pass k of the call writes: the last one `dst`, alternating backwards from there
+        auto target_of = [&](std::uint64_t k) -> void *const * {
+            return ((total_passes - 1 - k) % 2) == 0 ? dst : scratch;
+        };
+
+        // ---- passes behind a source that is still arriving (ststhip.h, ststhip_set_source_arrival) ----
+        // frontier[p] = rows [0, frontier[p]) of pass p are done (or queued).  When block k has arrived, rows
+        // [0, end_k) of the source are there and pass p may advance to end_k - (p + 1) * g: a tile of pass p reads g rows
+        // beyond its own on both sides in the output of pass p - 1, and pass p - 1 has come g rows further.  The tiles of
+        // one block (its "column": p = 0, 1, ...) form a chain on one stream; the columns of consecutive blocks run on
+        // different streams, one pass apart (a tile waits for the tiles of the pass before it that overlap what it
+        // reads -- the same tiles are the last readers of the rows it overwrites, two passes share a buffer set).
+        if (stream_limit > 0 && rc == STSTHIP_OK) {
+            struct Tile {
+                std::uint64_t begin, end;
+                hipEvent_t done;
+                hipStream_t on;
+            };
+            std::vector<hipStream_t> tile_lane(1, s), extra;
+            if (side_streams_for(s, 1, extra))
+                tile_lane.push_back(extra[0]);
+            {
+                // (the scratch planes were allocated for work on `s`)
+                hipEvent_t begin = new_event();
+                ordered(hipEventRecord(begin, s), "hipEventRecord");
+                for (std::size_t v = 1; v < tile_lane.size(); v++)
+                    ordered(hipStreamWaitEvent(tile_lane[v], begin, 0), "hipStreamWaitEvent");
+            }
+            std::vector<std::vector<Tile>> tiles(stream_limit);
+            std::vector<std::uint64_t> frontier(stream_limit, 0);
+            // How deep a column goes: as deep as it takes to keep the chip busy until the next block is there -- and a
+            // little busier: a tile of one block's rows cannot fill the chip on its own (a 2048 x 16384 tile of the
+            // Jacobi example runs at 46 % of the whole grid's rate), two columns side by side do better, so the aim is ONE
+            // or two earlier columns still running when a block arrives.  None: the chip has idled, and the column
+            // before is timed against the blocks' arrival; three or more: the chip is behind, the next column goes
+            // less deep (passes that are begun are completed by the last column whatever the later columns did).
+            std::uint64_t row_bytes_all_planes = 0;
+            for (unsigned p = 0; p < n_planes; p++)
+                row_bytes_all_planes += dom->pitch * desc->plane_elem_size[p];
+            std::uint64_t deep_now = std::min<std::uint64_t>(stream_limit, 16);
+            deep_now = std::max<std::uint64_t>(deep_now - deep_now % quantum, quantum);
+            std::uint64_t deepest = 0;
+            std::vector<hipEvent_t> clocks; // timing events of the columns: begin, end
+            g_launch_concurrency = 2;
+            const bool narrate = std::getenv("STSTHIP_TRACE_STREAM") != nullptr; // (a debugging aid: host times to stderr)
+            auto host_ms = [&] {
+                return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - started).count();
+            };
+            for (std::size_t k = 0; k < arrival.size() && rc == STSTHIP_OK; k++) {
+                const double waiting_since = host_ms();
+                ordered(hipEventSynchronize(static_cast<hipEvent_t>(arrival[k].ready)), "hipEventSynchronize");
+                if (rc != STSTHIP_OK)
+                    break;
+                const bool last = k + 1 == arrival.size();
+                int behind = 0; // earlier columns that are still running
+                for (std::size_t j = 0; j < k; j++)
+                    behind += hipEventQuery(clocks[2 * j + 1]) == hipSuccess ? 0 : 1;
+                if (narrate)
+                    std::fprintf(stderr, "[ststhip] block %zu: host waited from %.2f to %.2f ms of the call, %d columns running", k,
+                                 waiting_since, host_ms(), behind);
+                if (k > 0 && !last) {
+                    std::uint64_t want = deep_now;
+                    if (behind == 0) {
+                        // t = what a tile of the column before took (alone, or beside the one before it: the estimate
+                        // is then on the careful side); two columns side by side finish a tile every 0.8 t
+                        // (a block's time over PCIe by its bytes at 55 GB/s: the gaps between the arrival events are no
+                        // measure -- the first blocks of an upload have been seen to arrive 5-6 ms ahead of the rest)
+                        float column_ms = 0.0f;
+                        const double block_ms = double(std::min(arrival[k].row_end, H) - std::min(arrival[k - 1].row_end, H)) *
+                                                double(row_bytes_all_planes) / 55e6;
+                        double grow = 1.25;
+                        if (hipEventElapsedTime(&column_ms, clocks[2 * (k - 1)], clocks[2 * (k - 1) + 1]) == hipSuccess &&
+                            column_ms > 0.0f)
+                            grow = std::min(4.0, std::max(1.25, block_ms / (0.8 * double(column_ms))));
+                        if (narrate)
+                            std::fprintf(stderr, " (column before: %.2f ms, block: %.2f ms)", column_ms, block_ms);
+                        want = std::uint64_t(double(deep_now) * grow + 0.5);
+                    } else if (behind >= 3) {
+                        want = deep_now * 3 / 4;
+                    }
+                    want -= want % quantum;
+                    deep_now = std::min(std::max<std::uint64_t>(want, quantum), stream_limit);
+                }
+                deepest = std::max(deepest, deep_now);
+                const std::uint64_t arrived = last ? H : std::min(arrival[k].row_end, H);
+                hipStream_t on = tile_lane[k % tile_lane.size()];
+                hipEvent_t c0 = nullptr, c1 = nullptr;
+                ordered(hipEventCreate(&c0), "hipEventCreate");
+                ordered(hipEventCreate(&c1), "hipEventCreate");
+                clocks.push_back(c0);
+                clocks.push_back(c1);
+                if (rc != STSTHIP_OK)
+                    break;
+                ordered(hipEventRecord(c0, on), "hipEventRecord");
+                // (the last column completes every pass that was begun)
+                for (std::uint64_t p = 0; p < (last ? deepest : deep_now) && rc == STSTHIP_OK; p++) {
+                    const std::uint64_t above = p == 0 ? arrived : frontier[p - 1];
+                    const std::uint64_t upto = above >= H ? H : (above > tile_g ? above - tile_g : 0);
+                    if (upto <= frontier[p])
+                        break;
+                    const std::uint64_t from_row = frontier[p];
+                    if (p > 0)
+                        for (Tile const &t : tiles[p - 1])
+                            if (t.on != on && t.end + tile_g > from_row && t.begin < upto + tile_g)
+                                ordered(hipStreamWaitEvent(on, t.done, 0), "hipStreamWaitEvent");
+                    g_target_holds_constants = p >= 2 ? 1 : 0;
+                    rc = sweep(ctx, dom, p == 0 ? src : const_cast<const void *const *>(target_of(p - 1)), target_of(p),
+                               from_row, upto, iteration_offset + p * tile_depth, tile_depth, on);
+                    n_launches++;
+                    Tile t{from_row, upto, new_event(), on};
+                    ordered(hipEventRecord(t.done, on), "hipEventRecord");
+                    tiles[p].push_back(t);
+                    frontier[p] = upto;
+                }
+                ordered(hipEventRecord(c1, on), "hipEventRecord");
+                if (narrate)
+                    std::fprintf(stderr, ", column of %llu passes queued by %.2f ms\n",
+                                 (unsigned long long)(last ? deepest : deep_now), host_ms());
+                if (last)
+                    streamed = deepest;
+            }
+            for (std::size_t v = 1; v < tile_lane.size(); v++) {
+                hipEvent_t done = new_event();
+                ordered(hipEventRecord(done, tile_lane[v]), "hipEventRecord");
+                ordered(hipStreamWaitEvent(s, done, 0), "hipStreamWaitEvent");
+            }
+            if (narrate && rc == STSTHIP_OK && hipStreamSynchronize(s) == hipSuccess) {
+                for (std::size_t k = 0; 2 * k + 1 < clocks.size(); k++) {
+                    float ms = 0.0f, since = 0.0f;
+                    (void)hipEventElapsedTime(&ms, clocks[2 * k], clocks[2 * k + 1]);
+                    (void)hipEventElapsedTime(&since, clocks[0], clocks[2 * k]);
+                    std::fprintf(stderr, "[ststhip] column %zu ran from %.2f for %.2f ms\n", k, since, ms);
+                }
+                std::fprintf(stderr, "[ststhip] streamed passes done at %.2f ms of the call\n", host_ms());
+            }
+            for (hipEvent_t ev : clocks)
+                if (ev)
+                    (void)hipEventDestroy(ev);
+            g_launch_concurrency = 1;
+            g_target_holds_constants = 0;
+            // every pass that was begun is complete now (the last block's column took each of them to the last row)
+            for (std::uint64_t p = 0; p < streamed && rc == STSTHIP_OK; p++)
+                if (frontier[p] != H)
+                    rc = fail(STSTHIP_ERR_INVALID, "internal: a streamed pass is incomplete");
+            if (rc == STSTHIP_OK && streamed > 0) {
+                plan(n_iterations - streamed * tile_depth);
+                // (a probing call's plans differ in length by whole pairs of passes)
+                if ((streamed + depths.size()) % 2 != total_passes % 2)
+                    rc = fail(STSTHIP_ERR_INVALID, "internal: the plan behind the streamed passes has another parity");
+                strips = suggest_row_strips(H, dom->global_width, desc->strip_width, g_max, depths.size());
+            }
+        }
+
         // streams of the strips: strip 0 runs on the caller's stream
         std::vector<hipStream_t> lane(strips, s);
         if (strips > 1 && rc == STSTHIP_OK) {
@@ -1381,8 +1640,8 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         g_launch_concurrency = strips;
 
         // the last pass must land in dst; the input is never written
-        const void *const *from = src;
-        std::uint64_t iteration = iteration_offset;
+        const void *const *from = streamed ? const_cast<const void *const *>(target_of(streamed - 1)) : src;
+        std::uint64_t iteration = iteration_offset + streamed * tile_depth;
         // a point in time on every stream of the call: everything queued so far has finished before `ev`, nothing
         // queued later starts before it (the boundaries of the depth probes' timed groups)
         auto fence_all = [&](hipEvent_t ev) {
@@ -1425,11 +1684,10 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                     tuned_depths()[TunedKey{desc->tune_key, H, dom->global_width}] = take_alt ? alt : deep;
                 }
             }
-            const bool into_dst = ((depths.size() - 1 - pass) % 2) == 0;
-            void *const *to = into_dst ? dst : scratch;
+            void *const *to = target_of(streamed + pass);
             // targets alternate, and every pass writes all rows: from the third pass on the target already holds
             // what the pass before the previous one stored there, in particular the fields that never change
-            g_target_holds_constants = pass >= 2 ? 1 : 0;
+            g_target_holds_constants = streamed + pass >= 2 ? 1 : 0;
             const std::uint64_t g = std::uint64_t(depths[pass]) * desc->halo_depth_per_generation;
             hipEvent_t t0 = nullptr, t1 = nullptr;
             if (profiling) {
@@ -1509,6 +1767,13 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             ordered(hipStreamWaitEvent(s, done, 0), "hipStreamWaitEvent");
         }
     }
+    if (streamed > 0 && std::getenv("STSTHIP_TRACE_STREAM")) {
+        const double queued = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - started).count();
+        (void)hipStreamSynchronize(s);
+        std::fprintf(stderr, "[ststhip] all %zu + %llu passes queued at %.2f ms, done at %.2f ms of the call\n", depths.size(),
+                     (unsigned long long)streamed, queued,
+                     std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - started).count());
+    }
     if (rc == STSTHIP_OK && (blocking || profiling)) {
         hipError_t err = hipStreamSynchronize(s);
         if (err != hipSuccess)
@@ -1538,6 +1803,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
         info->kernel_time_s = kernel_s;
         info->n_launches = n_launches;
         info->n_processed_cells = n_iterations * dom->global_height * dom->global_width;
+        info->n_streamed_passes = streamed;
     }
     return rc;
 }

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 
 def test_abi_version(built_lib):
-    assert built_lib.ststhip_abi_version() == 5
+    assert built_lib.ststhip_abi_version() == 6
 
 
 def test_options_come_from_the_environment_once(built_lib, monkeypatch):

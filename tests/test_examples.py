@@ -155,6 +155,48 @@ def test_hotspot_hip_bit_exact(tmp_path, oracle, binary_name):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("its", [40, 333])
+def test_jacobi_hip_follows_its_upload_block_by_block(tmp_path, oracle, its):
+    """The unchanged example with its grid uploaded in row blocks and the first passes run as row tiles behind them
+    (hip/Grid.hpp start_upload_in_blocks, ststhip_set_source_arrival; blocks of 1 MiB so that a small grid has
+    eight): the output file equals the oracle's, and the run with one copy in front of the first pass."""
+    binary = exe("jacobi_Jacobi5General_hip")
+    coef = ["0.2", "0.21", "0.19", "0.22", "0.18"]
+    H, W = 2048, 1024
+    want = oracle.jacobi("Jacobi5General", [float(c) for c in coef], oracle.jacobi_init(H, W), its, halo=0.0, n_threads=8)
+    for mode in ({"STSTHIP_UPLOAD_BLOCK_MIB": "1"}, {"STSTHIP_STREAM_UPLOAD": "0"}):
+        out_file = tmp_path / "out.bin"
+        res = subprocess.run([binary, str(H), str(W), str(its), str(out_file)] + coef, check=True, capture_output=True,
+                             env=dict(os.environ, STSTHIP_TRACE_STREAM="1", **mode), timeout=600)
+        followed = b"[ststhip] block 7" in res.stderr
+        assert followed == ("STSTHIP_UPLOAD_BLOCK_MIB" in mode), res.stderr.decode()[-400:]
+        got = np.fromfile(out_file, dtype=np.float32).reshape(H, W)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary_name", ["hotspot_hip", "hotspot_aos_hip"])
+def test_hotspot_hip_follows_its_upload_block_by_block(tmp_path, oracle, binary_name):
+    """... and with per-field planes: every block is scattered into the planes behind its copy."""
+    binary = exe(binary_name)
+    n, its = 1024, 150
+    rng = np.random.default_rng(9)
+    temp = (30 + rng.random((n, n), dtype=np.float32)).astype(np.float32)
+    power = (rng.random((n, n), dtype=np.float32) * 0.5).astype(np.float32)
+    temp.tofile(tmp_path / "temp.bin")
+    power.tofile(tmp_path / "power.bin")
+    res = subprocess.run([binary, str(n), str(n), str(its), str(tmp_path / "temp.bin"), str(tmp_path / "power.bin"),
+                          str(tmp_path / "out.bin")], check=True, capture_output=True,
+                         env=dict(os.environ, STSTHIP_TRACE_STREAM="1", STSTHIP_UPLOAD_BLOCK_MIB="1"), timeout=600)
+    assert b"[ststhip] block 3" in res.stderr, res.stderr.decode()[-400:]
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.float32).reshape(n, n)
+    cells = np.zeros((n, n), dtype=oracle.HOTSPOT_CELL)
+    cells["temp"], cells["power"] = temp, power
+    want = oracle.hotspot(oracle.hotspot_params(n, n), cells, its, n_threads=8)["temp"]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 # ------------------------------------------------------------------ the reference's own GPU compile mode (fused multiply-adds)
 # The reference's CMake targets give its GPU builds no -ffp-contract flag (CMakeLists.txt:46-51): a*b+c is fused there, and
 # north_star asks for "stated fp32 tolerance" for Jacobi and HotSpot, not bit-equality.  The *_hip_fma binaries are the
