@@ -562,7 +562,8 @@ def example_leg(binary_name, args, what, cells):
 
 FIRST_USE_NOTE = ("outside Walltime (as the reference excludes queue creation, cuda/StencilUpdate.hpp:124-128): creation "
                   "of the runtime's stream set and the copy engines' first use (a 1 MiB copy each way), which happen "
-                  "when the host first asks the runtime for pinned memory, i.e. when the example allocates its grid")
+                  "when the host first asks the runtime for pinned memory, i.e. when the example allocates its grid; "
+                  "and the load of the update's code object, which happens when the StencilUpdate object is built")
 
 
 def profile_legs(torch, capi, device, stream, gens):
@@ -959,7 +960,9 @@ def main():
                     "jacobi_Jacobi5General_hip", args_j,
                     f"build/examples/jacobi_Jacobi5General_hip 16384 16384 {gens} /dev/null 0.2 x5: the reference's unchanged "
                     "source on stencil::hip, bit-identical to the cpu backend (-ffp-contract=off); the application's own "
-                    "Walltime, which includes the upload of the 1 GiB grid; min of 3 after a warm-up; " + FIRST_USE_NOTE,
+                    "Walltime, which includes the upload of the 1 GiB grid -- in row blocks that the pass driver follows "
+                    "(ABI 6, DESIGN.md 3.7; STSTHIP_STREAM_UPLOAD=0: one copy in front of the first pass, 0.083 s); min of 3 "
+                    "after a warm-up; " + FIRST_USE_NOTE,
                     16384 * 16384 * gens)
                 legs["template_api_fma"] = example_leg(
                     "jacobi_Jacobi5General_hip_fma", args_j,
