@@ -36,14 +36,19 @@ template <typename Cell> class Grid {
         // written (or freed) before it has been read
         ststhip_event upload_event = nullptr;
         bool upload_pending = false;
-        // events of an upload in row blocks (start_upload_in_blocks); the last one is what wait_upload() waits for
+        // events of an upload in row blocks (start_upload_in_blocks): per block "copied" and "ready" (the kernel a host
+        // runs behind the copy has finished); `work_pending`: the last "ready" has not been waited for
         std::vector<ststhip_event> block_events;
+        ststhip_event last_ready = nullptr;
+        bool work_pending = false;
 
         explicit Storage(sycl::range<2> extent) : extent(extent) {}
         Storage(Storage const &) = delete;
         ~Storage() {
             if (upload_pending)
                 ststhip_event_synchronize(upload_event);
+            if (work_pending)
+                ststhip_event_synchronize(last_ready); // (a kernel that still reads the device cells)
             if (upload_event)
                 ststhip_event_destroy(upload_event);
             for (ststhip_event ev : block_events)
@@ -85,6 +90,10 @@ template <typename Cell> class Grid {
             if (upload_pending) {
                 internal::check(ststhip_event_synchronize(upload_event), "grid upload");
                 upload_pending = false;
+            }
+            if (work_pending) {
+                internal::check(ststhip_event_synchronize(last_ready), "grid upload");
+                work_pending = false;
             }
         }
         // The device copy is up to date for work queued on `s` after this call; the host does not wait for the
@@ -152,7 +161,9 @@ template <typename Cell> class Grid {
                     internal::check(ststhip_event_record(ready, work), "grid upload");
                 }
                 blocks.push_back(ststhip_source_block{end, ready});
+                last_ready = ready;
             }
+            work_pending = has_work;
             // (what wait_upload() waits for: the pinned mirror has been read)
             internal::check(ststhip_event_record(upload_event, up), "grid upload");
             upload_pending = true;

@@ -506,6 +506,15 @@ int ststhip_block_create(const char *app, const void *tf_params, const void *hal
                          uint64_t total_cols, int rank, int mesh_rows, int mesh_cols, ststhip_comm comm,
                          ststhip_exchange_fn exchange_rows, void *exchange_rows_ctx,
                          ststhip_exchange_fn exchange_cols, void *exchange_cols_ctx, ststhip_strip *block);
+/* The same for a sweep that is not in the registry (ABI 6): the launch callback + description of ststhip_run_passes, as
+ * ststhip_strip_create_custom takes them -- what stencil::hip::BlockUpdate<F> (a user's transition function on a mesh of
+ * GPUs) is built on.  The callback must honour the column range of the calling thread's launches
+ * (ststhip_launch_columns) and the column geometry of the domain it is handed (col_origin / local_cols); a callback that
+ * goes through the C++ templates' launcher (hip/internal/Sweep.hpp: launch_sweep) does. */
+int ststhip_block_create_custom(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc, uint64_t total_rows,
+                                uint64_t total_cols, int rank, int mesh_rows, int mesh_cols, ststhip_comm comm,
+                                ststhip_exchange_fn exchange_rows, void *exchange_rows_ctx,
+                                ststhip_exchange_fn exchange_cols, void *exchange_cols_ctx, ststhip_strip *block);
 /* global rows and columns this block owns */
 int ststhip_block_geometry(ststhip_strip block, uint64_t *row_begin, uint64_t *row_end, uint64_t *col_begin,
                            uint64_t *col_end);

@@ -241,6 +241,7 @@ def load():
         "ststhip_comm_set_mesh": [vp, C.c_int, C.c_int],
         "ststhip_comm_exchange_columns": [vp, C.c_int, pp, pp, pp, pp, C.POINTER(sz), vp],
         "ststhip_block_create": [C.c_char_p, vp, vp, u64, u64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, pp],
+        "ststhip_block_create_custom": [vp, vp, vp, u64, u64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, pp],
         "ststhip_block_geometry": [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)],
         "ststhip_block_upload": [vp, C.c_uint, vp, sz],
         "ststhip_block_download": [vp, C.c_uint, vp, sz],

@@ -35,6 +35,16 @@ static int hip_fail(hipError_t err, const char *what) {
 }
 
 // ------------------------------------------------------------------ options (environment, read once)
+// Has everything recorded into `event` finished?  (hipEventQuery's "not ready" is an ERROR of the calling thread as far
+// as hipGetLastError is concerned: left in place, the next kernel launch that checks hipGetLastError reports it as its own
+// -- seen with several blocks as threads of one process, where a pooled buffer's release event is still pending.)
+static bool event_done(hipEvent_t event) {
+    if (hipEventQuery(event) == hipSuccess)
+        return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 static int env_int(const char *name, int fallback) {
     const char *v = std::getenv(name);
     return (v && *v) ? std::atoi(v) : fallback;
@@ -621,7 +631,7 @@ static int take_free_block(std::size_t bucket, hipStream_t stream, bool for_host
         auto pick = r.free_blocks.end();
         for (auto it = range.first; it != range.second; ++it) {
             Runtime::FreeBlock &b = it->second;
-            if (b.released && hipEventQuery(b.released) == hipSuccess) {
+            if (b.released && event_done(b.released)) {
                 (void)hipEventDestroy(b.released);
                 b.released = nullptr;
             }
@@ -1497,7 +1507,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                 const bool last = k + 1 == arrival.size();
                 int behind = 0; // earlier columns that are still running
                 for (std::size_t j = 0; j < k; j++)
-                    behind += hipEventQuery(clocks[2 * j + 1]) == hipSuccess ? 0 : 1;
+                    behind += event_done(clocks[2 * j + 1]) ? 0 : 1;
                 if (narrate)
                     std::fprintf(stderr, "[ststhip] block %zu: host waited from %.2f to %.2f ms of the call, %d columns running", k,
                                  waiting_since, host_ms(), behind);
@@ -2813,26 +2823,13 @@ int block_advance(Strip *st, std::uint64_t iteration_offset, std::uint64_t n_gen
 
 extern "C" {
 
-int ststhip_block_create(const char *app, const void *tf_params, const void *halo_cell, uint64_t total_rows,
-                         uint64_t total_cols, int rank, int mesh_rows, int mesh_cols, ststhip_comm comm,
-                         ststhip_exchange_fn exchange_rows, void *exchange_rows_ctx,
-                         ststhip_exchange_fn exchange_cols, void *exchange_cols_ctx, ststhip_strip *block) {
-    const AppEntry *e = find_app(app);
-    if (!e)
-        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
-    if (!tf_params || !halo_cell || !block || mesh_rows < 1 || mesh_cols < 1 || rank < 0 || rank >= mesh_rows * mesh_cols ||
-        total_rows == 0 || total_cols == 0)
-        return fail(STSTHIP_ERR_INVALID, "bad block arguments");
-    if (!comm && ((mesh_rows > 1 && !exchange_rows) || (mesh_cols > 1 && !exchange_cols)))
-        return fail(STSTHIP_ERR_INVALID, "several blocks need a communicator or exchange callbacks for rows and columns");
-    if (int rc = ststhip_init(-1))
-        return rc;
-    Strip *st = new Strip;
+extern "C++" {
+namespace {
+// where a block lies in the mesh and whom it talks to
+void place_block(Strip *st, std::uint64_t total_rows, std::uint64_t total_cols, int rank, int mesh_rows, int mesh_cols,
+                 ststhip_comm comm, ststhip_exchange_fn exchange_rows, void *exchange_rows_ctx,
+                 ststhip_exchange_fn exchange_cols, void *exchange_cols_ctx) {
     st->is_block = true;
-    st->app = app;
-    st->params.assign(static_cast<const unsigned char *>(tf_params),
-                      static_cast<const unsigned char *>(tf_params) + std::max<std::uint32_t>(e->info.params_size, 1));
-    st->halo.assign(static_cast<const unsigned char *>(halo_cell), static_cast<const unsigned char *>(halo_cell) + e->info.cell_size);
     st->rank = rank;
     st->n_ranks = mesh_rows * mesh_cols;
     st->mesh_rows = mesh_rows;
@@ -2848,18 +2845,13 @@ int ststhip_block_create(const char *app, const void *tf_params, const void *hal
     st->total_cols = st->width = total_cols;
     strip_bounds(total_rows, mesh_rows, st->mesh_r, st->row_begin, st->row_end);
     strip_bounds(total_cols, mesh_cols, st->mesh_c, st->col_begin, st->col_end);
-    ststhip_domain whole = {};
-    whole.global_height = total_rows;
-    whole.global_width = total_cols;
-    whole.pitch = total_cols;
-    whole.local_rows = total_rows;
-    whole.local_cols = total_cols; // (a block: the sweeps run on cells, never on the packed words of the Game of Life)
-    const ststhip_domain *dom = &whole;
-    int rc = resolve_app(st->resolved, st->app.c_str(), st->params.data(), st->halo.data(), dom, nullptr, nullptr, false);
-    if (rc != STSTHIP_OK) {
-        delete st;
-        return rc;
-    }
+}
+
+// ghost depths, buffers and streams of a block whose sweep (st->resolved) is known; owns `st` from here on
+int finish_block(Strip *st, ststhip_strip *block) {
+    const std::uint64_t total_rows = st->total_rows, total_cols = st->total_cols;
+    const int mesh_rows = st->mesh_rows, mesh_cols = st->mesh_cols;
+    int rc = STSTHIP_OK;
     const ststhip_sweep_desc &d = st->resolved.desc;
     st->n_planes = d.n_planes;
     st->g_max = std::uint64_t(d.alt_generations && d.alt_generations < d.max_generations ? d.alt_generations : d.max_generations) *
@@ -2919,6 +2911,65 @@ int ststhip_block_create(const char *app, const void *tf_params, const void *hal
     }
     *block = st;
     return STSTHIP_OK;
+}
+} // namespace
+} // extern "C++"
+
+int ststhip_block_create(const char *app, const void *tf_params, const void *halo_cell, uint64_t total_rows,
+                         uint64_t total_cols, int rank, int mesh_rows, int mesh_cols, ststhip_comm comm,
+                         ststhip_exchange_fn exchange_rows, void *exchange_rows_ctx,
+                         ststhip_exchange_fn exchange_cols, void *exchange_cols_ctx, ststhip_strip *block) {
+    const AppEntry *e = find_app(app);
+    if (!e)
+        return fail(STSTHIP_ERR_UNKNOWN_APP, "unknown transition function");
+    if (!tf_params || !halo_cell || !block || mesh_rows < 1 || mesh_cols < 1 || rank < 0 || rank >= mesh_rows * mesh_cols ||
+        total_rows == 0 || total_cols == 0)
+        return fail(STSTHIP_ERR_INVALID, "bad block arguments");
+    if (!comm && ((mesh_rows > 1 && !exchange_rows) || (mesh_cols > 1 && !exchange_cols)))
+        return fail(STSTHIP_ERR_INVALID, "several blocks need a communicator or exchange callbacks for rows and columns");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    Strip *st = new Strip;
+    st->app = app;
+    st->params.assign(static_cast<const unsigned char *>(tf_params),
+                      static_cast<const unsigned char *>(tf_params) + std::max<std::uint32_t>(e->info.params_size, 1));
+    st->halo.assign(static_cast<const unsigned char *>(halo_cell), static_cast<const unsigned char *>(halo_cell) + e->info.cell_size);
+    place_block(st, total_rows, total_cols, rank, mesh_rows, mesh_cols, comm, exchange_rows, exchange_rows_ctx, exchange_cols,
+                exchange_cols_ctx);
+    ststhip_domain whole = {};
+    whole.global_height = total_rows;
+    whole.global_width = total_cols;
+    whole.pitch = total_cols;
+    whole.local_rows = total_rows;
+    whole.local_cols = total_cols; // (a block: the sweeps run on cells, never on the packed words of the Game of Life)
+    const ststhip_domain *dom = &whole;
+    int rc = resolve_app(st->resolved, st->app.c_str(), st->params.data(), st->halo.data(), dom, nullptr, nullptr, false);
+    if (rc != STSTHIP_OK) {
+        delete st;
+        return rc;
+    }
+    return finish_block(st, block);
+}
+
+int ststhip_block_create_custom(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_desc *desc, uint64_t total_rows,
+                                uint64_t total_cols, int rank, int mesh_rows, int mesh_cols, ststhip_comm comm,
+                                ststhip_exchange_fn exchange_rows, void *exchange_rows_ctx,
+                                ststhip_exchange_fn exchange_cols, void *exchange_cols_ctx, ststhip_strip *block) {
+    if (!sweep || !desc || !block || mesh_rows < 1 || mesh_cols < 1 || rank < 0 || rank >= mesh_rows * mesh_cols ||
+        total_rows == 0 || total_cols == 0)
+        return fail(STSTHIP_ERR_INVALID, "bad block arguments");
+    if (!comm && ((mesh_rows > 1 && !exchange_rows) || (mesh_cols > 1 && !exchange_cols)))
+        return fail(STSTHIP_ERR_INVALID, "several blocks need a communicator or exchange callbacks for rows and columns");
+    if (int rc = ststhip_init(-1))
+        return rc;
+    Strip *st = new Strip;
+    place_block(st, total_rows, total_cols, rank, mesh_rows, mesh_cols, comm, exchange_rows, exchange_rows_ctx, exchange_cols,
+                exchange_cols_ctx);
+    st->resolved.entry = nullptr; // the caller's sweep: no registry entry, no run window to maintain
+    st->resolved.trampoline = sweep;
+    st->resolved.ctx = ctx;
+    st->resolved.desc = *desc;
+    return finish_block(st, block);
 }
 
 int ststhip_block_geometry(ststhip_strip block, uint64_t *row_begin, uint64_t *row_end, uint64_t *col_begin,

@@ -83,3 +83,18 @@ def test_strip_update_template_with_user_functors(tmp_path, ranks):
     assert np.array_equal(many[ramp_at:ramp_at + 4 * cells], one[ramp_at:ramp_at + 4 * cells]), "Ramp"
     assert np.array_equal(many[plate_at:plate_at + 8 * cells], one[plate_at:plate_at + 8 * cells]), "Conduction"
     assert one[ramp_at:ramp_at + 4 * cells].view(np.float32).std() > 0
+
+
+@pytest.mark.gpu
+def test_block_update_template_with_user_functors():
+    """tests/cpp/block_template_test.hip: stencil::hip::BlockUpdate -- USER transition functions (time-dependent values,
+    sub-iterations and the cells' own coordinates on AoS cells; a two-field cell on per-field planes) on meshes of 1 x 1,
+    2 x 2, 1 x 3 and 3 x 1 blocks (threads of one process on cuda:0, ghost columns and rows through an in-process mailbox):
+    every mesh's assembled cells equal hip::StencilUpdate on the whole grid, bit for bit."""
+    binary = os.path.join(OUT, "block_template_test")
+    if not os.path.exists(binary):
+        pytest.fail("build/tests/block_template_test missing: run __graft_entry__.build()")
+    res = subprocess.run([binary], capture_output=True, timeout=600)
+    assert res.returncode == 0, (res.stdout + res.stderr).decode()[-2000:]
+    for mesh in (b"1 x 1", b"2 x 2", b"1 x 3", b"3 x 1"):
+        assert b"mesh " + mesh + b" equals hip::StencilUpdate" in res.stdout
