@@ -181,7 +181,11 @@ typedef struct {
                                       driver starts on the blocks that have arrived (ststhip_set_source_arrival); 0 = one
                                       copy in front of the first pass                                                   */
     int32_t upload_block_mib;      /* size of those blocks; 0 = the rule of ststhip_suggest_upload_blocks              */
-    int32_t reserved[5];
+    int32_t skewed_strips;         /* pass driver, two row strips: 1 (default) = their common boundary moves up by a launch's
+                                      ghost rows from pass to pass (no boundary bands: one launch per strip and pass, the
+                                      upper strip never waits for the lower one); 0 = fixed strips with boundary bands on
+                                      streams of their own (rounds 1-3)                                                   */
+    int32_t reserved[4];
 } ststhip_options;
 const ststhip_options *ststhip_get_options(void);
 int ststhip_reload_options(void);

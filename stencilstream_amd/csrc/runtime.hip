@@ -94,6 +94,7 @@ static ststhip_options read_options() {
     o.exchange_every = env_int("STSTHIP_EXCHANGE_EVERY", 0);
     o.tune_depth = env_int("STSTHIP_TUNE_DEPTH", 1);
     o.stream_upload = env_int("STSTHIP_STREAM_UPLOAD", 1);
+    o.skewed_strips = env_int("STSTHIP_SKEWED_STRIPS", 1);
     o.upload_block_mib = env_int("STSTHIP_UPLOAD_BLOCK_MIB", 0);
     return o;
 }
@@ -1645,6 +1646,16 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             for (int v = 0; v < strips; v++)
                 ordered(hipStreamWaitEvent(band_lane[v], begin, 0), "hipStreamWaitEvent");
         }
+        // Strips with moving boundaries instead of strips with boundary bands (see the pass loop).  The boundaries move
+        // around their places of rest: by what the call's plan moves them, at most a quarter of a strip's rows.
+        std::uint64_t skew_span = 0;
+        for (std::size_t i = 0; i < depths.size(); i++)
+            skew_span += std::uint64_t(std::max(depths[i], i ? depths[i - 1] : 0u)) * desc->halo_depth_per_generation;
+        skew_span = std::min<std::uint64_t>(skew_span, std::min<std::uint64_t>(H / std::uint64_t(2 * strips), 2048 + 2 * g_max));
+        const bool skewed_strips = strips >= 2 && !profiling && opt().skewed_strips != 0 &&
+                                   H >= std::uint64_t(strips) * 32 * g_max && skew_span >= 2 * g_max;
+        std::uint64_t skew_offset = 0, skew_g_before = 0; // how far below their highest places the boundaries are
+        std::vector<hipEvent_t> skew_done(strips, nullptr); // per strip: its launch of the previous pass
         std::vector<hipEvent_t> bands_done(strips, nullptr);    // per strip: bands of the previous pass
         std::vector<hipEvent_t> interior_done(strips, nullptr); // per strip: interior of the previous pass
         g_launch_concurrency = strips;
@@ -1706,6 +1717,44 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                 ordered(hipEventRecord(t0, s), "hipEventRecord");
             }
             std::vector<hipEvent_t> bands_now(strips, nullptr), interior_now(strips, nullptr);
+            if (skewed_strips) {
+                // Strips whose common boundaries move UP by a launch's ghost rows from pass to pass (the larger of this
+                // pass's and the one's before): a strip of pass p then reads nothing the strip BELOW it wrote in pass
+                // p - 1 and overwrites nothing that one read -- it waits for the strip ABOVE it of the pass before and
+                // for its own, nothing else; the uppermost strip's launches are a chain of their own.  No boundary
+                // bands, one launch per strip and pass.  When the boundaries have moved a span, every strip waits for
+                // the one below it once and the boundaries start over.
+                const std::uint64_t shift = std::max(g, skew_g_before);
+                bool restart = false;
+                if (skew_offset + shift > skew_span) {
+                    skew_offset = 0;
+                    restart = true;
+                } else {
+                    skew_offset += shift;
+                }
+                skew_g_before = g;
+                std::vector<hipEvent_t> done_now(strips, nullptr);
+                for (int v = 0; v < strips && rc == STSTHIP_OK; v++) {
+                    const std::uint64_t top = v == 0 ? 0 : bound[v] + skew_span / 2 - skew_offset;
+                    const std::uint64_t end = v + 1 == strips ? H : bound[v + 1] + skew_span / 2 - skew_offset;
+                    if (v > 0 && skew_done[v - 1])
+                        ordered(hipStreamWaitEvent(lane[v], skew_done[v - 1], 0), "hipStreamWaitEvent");
+                    if (restart && v + 1 < strips && skew_done[v + 1])
+                        ordered(hipStreamWaitEvent(lane[v], skew_done[v + 1], 0), "hipStreamWaitEvent");
+                    rc = sweep(ctx, dom, from, to, top, end, iteration, depths[pass], lane[v]);
+                    n_launches++;
+                    done_now[v] = new_event();
+                    ordered(hipEventRecord(done_now[v], lane[v]), "hipEventRecord");
+                }
+                skew_done.swap(done_now);
+                if (profiling) {
+                    ordered(hipEventRecord(t1, s), "hipEventRecord");
+                    timed.emplace_back(t0, t1);
+                }
+                from = const_cast<const void *const *>(to);
+                iteration += depths[pass];
+                continue;
+            }
             for (int v = 0; v < strips && rc == STSTHIP_OK; v++) {
                 const std::uint64_t a = bound[v], b = bound[v + 1];
                 if (strips == 1) {

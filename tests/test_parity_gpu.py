@@ -1302,3 +1302,26 @@ def test_no_scratch_at_any_registered_depth(gpu):
             depth //= 2
     assert checked >= 100
     assert not offenders, offenders
+
+
+@pytest.mark.parametrize("strips", ["2", "3"])
+def test_row_strips_with_moving_boundaries_start_over(gpu, oracle, monkeypatch, strips):
+    """The pass driver's row strips with boundaries that move up by a launch's ghost rows per pass (ststhip_options::
+    skewed_strips): 700 generations on 2048 rows move them further than their span (a quarter of a strip at most), so they
+    start over in the middle of the call -- the one pass in which every strip also waits for the one below it.  Two and
+    three strips, general coefficients (8 generations per launch) and the uniform form (16), against the oracle and
+    against the scheme with fixed strips and boundary bands."""
+    from stencilstream_amd import update as U
+
+    monkeypatch.setenv("STSTHIP_VIRTUAL_STRIPS", strips)
+    monkeypatch.setenv("STSTHIP_NARROW_FORM_KCELLS", "0")
+    rng = np.random.default_rng(int(strips))
+    grid = rng.random((2048, 1024), dtype=np.float32)
+    for coef in ([0.11, 0.19, 0.23, 0.31, 0.16], [0.2] * 5):
+        want = oracle.jacobi("Jacobi5General", coef, grid, 700, halo=0.0, n_threads=8)
+        monkeypatch.setenv("STSTHIP_SKEWED_STRIPS", "1")
+        moving = run_hip(U.jacobi("Jacobi5General", coef), grid, 700, halo=np.float32(0.0))
+        monkeypatch.setenv("STSTHIP_SKEWED_STRIPS", "0")
+        fixed = run_hip(U.jacobi("Jacobi5General", coef), grid, 700, halo=np.float32(0.0))
+        assert np.array_equal(bits(moving), bits(want)), coef
+        assert np.array_equal(bits(fixed), bits(want)), coef
