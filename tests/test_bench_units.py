@@ -49,9 +49,11 @@ def test_committed_counters_describe_every_kernel_leg(bench):
 
 
 def test_counters_are_refused_for_another_launch_plan(bench):
-    leg, why = bench.leg_counters("headline", 252)
+    profiled = json.load(open(bench.COUNTER_FILE))["legs"]["headline"]["launches_per_call"]
+    assert profiled == 126  # two strips with a moving boundary: two launches per pass of 16 generations
+    leg, why = bench.leg_counters("headline", profiled)
     assert leg is not None and why is None
-    leg, why = bench.leg_counters("headline", 251)
+    leg, why = bench.leg_counters("headline", profiled + 1)
     assert leg is None and "launch plan" in why
     leg, why = bench.leg_counters("no_such_leg", None)
     assert leg is None and "no leg" in why
