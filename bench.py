@@ -24,8 +24,8 @@ What the JSON line carries besides the contract's fields:
                 (8 B per cell-update x generations per launch) over the launch time -- with temporal blocking
                 this exceeds the 8 TB/s peak by design (each cell moves once per T generations) --, `traffic` the
                 HBM bytes of such a launch from the PMC passes.  The PHYSICAL fractions lead with `timed_path`:
-                HBM bytes and VALU wave-instructions of ONE TIMED STEP (all its launches: two row strips side by
-                side, their bands) from the committed PMC passes of this file's own legs
+                HBM bytes and VALU wave-instructions of ONE TIMED STEP (all its launches: two row strips with a
+                moving boundary, side by side) from the committed PMC passes of this file's own legs
                 (profiles/r04_bench_counters.json, tools/profile_bench_r04.sh) over THIS run's ms_per_step;
                 `full_grid_launch` is the same per launch over kernel_ms.  VALU fractions on both bases (the guide's
                 2 cycles at 2.4 GHz, this repository's measured 1.09 ns); `bound` is derived from the fractions.
@@ -497,7 +497,7 @@ def kernel_legs(torch, capi, device, stream, gens, size=16384):
         # what roofline.kernel_ms times)
         "headline": {"setup": jacobi("jacobi5general", COEF, square), "bytes": 8,
                      "what": f"Jacobi5General {size}^2, coefficients 5 x 0.2, halo 0, centred-square input: the uniform-"
-                             "coefficient form, two row strips with their bands (the path `value` times)"},
+                             "coefficient form, two row strips with a moving boundary (the path `value` times)"},
         "headline_full_grid": {"setup": jacobi("jacobi5general", COEF, square, n=15 * T, env={"STSTHIP_VIRTUAL_STRIPS": "1"}),
                                "bytes": 8, "what": "the same kernel as full-grid launches of the full depth on one stream"},
         "random_init": {"setup": jacobi("jacobi5general", COEF, random), "bytes": 8,
@@ -897,7 +897,7 @@ def main():
                         "launch time of a FULL-GRID launch (kernel_ms, HIP events); above 1 because a launch advances T "
                         "generations while a cell crosses HBM once (temporal blocking).  The physical fractions: "
                         "`timed_path` = HBM bytes and VALU wave-instructions of ONE TIMED STEP (all its launches: two row "
-                        "strips side by side, their bands on streams of their own; PMC) over this run's ms_per_step -- what "
+                        "strips with a moving boundary, side by side; PMC) over this run's ms_per_step -- what "
                         "`value` is; `full_grid_launch` = the same counters per full-grid launch over kernel_ms.  `bound` is "
                         "the timed path's.",
             }
