@@ -1325,3 +1325,24 @@ def test_row_strips_with_moving_boundaries_start_over(gpu, oracle, monkeypatch, 
         fixed = run_hip(U.jacobi("Jacobi5General", coef), grid, 700, halo=np.float32(0.0))
         assert np.array_equal(bits(moving), bits(want)), coef
         assert np.array_equal(bits(fixed), bits(want)), coef
+
+
+@pytest.mark.parametrize("strips,rows", [("2", 2050), ("3", 2052)])
+def test_row_strips_with_moving_boundaries_while_the_depth_is_probed(gpu, oracle, monkeypatch, strips, rows):
+    """... and in a call that times its own first passes at two depths (launches of 16, 16, 16, 8, 8, 8, 8 generations and
+    then the winner's): the boundaries move by the LARGER of a pass's ghost rows and the ones of the pass before, whichever
+    way the depth changes.  A grid shape no other test uses, so that the call probes."""
+    from stencilstream_amd import capi
+    from stencilstream_amd import update as U
+
+    monkeypatch.setenv("STSTHIP_VIRTUAL_STRIPS", strips)
+    monkeypatch.setenv("STSTHIP_NARROW_FORM_KCELLS", "0")
+    monkeypatch.setenv("STSTHIP_SKEWED_STRIPS", "1")
+    rng = np.random.default_rng(rows)
+    grid = rng.random((rows, 1024), dtype=np.float32)
+    coef = [0.12, 0.18, 0.24, 0.3, 0.16]
+    assert capi.app_tuned_depth("jacobi5general", rows, 1024) == 0
+    got = run_hip(U.jacobi("Jacobi5General", coef), grid, 300, halo=np.float32(0.0))
+    assert capi.app_tuned_depth("jacobi5general", rows, 1024) in (8, 16), "the call did not probe"
+    want = oracle.jacobi("Jacobi5General", coef, grid, 300, halo=0.0, n_threads=8)
+    assert np.array_equal(bits(got), bits(want))
