@@ -185,7 +185,10 @@ typedef struct {
                                       ghost rows from pass to pass (no boundary bands: one launch per strip and pass, the
                                       upper strip never waits for the lower one); 0 = fixed strips with boundary bands on
                                       streams of their own (rounds 1-3)                                                   */
-    int32_t reserved[4];
+    int32_t strip_substrips;       /* strip driver: a rank's strip as two sub-strips with a moving boundary (two launches in
+                                      flight); -1 (default) = the rule of ststhip_suggest_row_strips on the strip's cells,
+                                      1 = never, 2 = wherever the strip is tall enough                                  */
+    int32_t reserved[3];
 } ststhip_options;
 const ststhip_options *ststhip_get_options(void);
 int ststhip_reload_options(void);

@@ -147,8 +147,8 @@ class Options(C.Structure):
                    "two_strips_permille_outer", "strip_skew_permille", "bands_beside_interior", "band_stream_priority",
                    "bands_apart", "bands_one_launch", "comm_stream_priority", "jacobi_fastpath", "conway_fastpath",
                    "prepare_streams", "host_cache_mib", "tune_depth", "exchange_every", "stream_upload",
-                   "upload_block_mib", "skewed_strips")] + \
-               [("reserved", C.c_int32 * 4)]
+                   "upload_block_mib", "skewed_strips", "strip_substrips")] + \
+               [("reserved", C.c_int32 * 3)]
 
 
 _lib = None

@@ -95,6 +95,7 @@ static ststhip_options read_options() {
     o.tune_depth = env_int("STSTHIP_TUNE_DEPTH", 1);
     o.stream_upload = env_int("STSTHIP_STREAM_UPLOAD", 1);
     o.skewed_strips = env_int("STSTHIP_SKEWED_STRIPS", 1);
+    o.strip_substrips = env_int("STSTHIP_STRIP_SUBSTRIPS", -1);
     o.upload_block_mib = env_int("STSTHIP_UPLOAD_BLOCK_MIB", 0);
     return o;
 }
@@ -2218,6 +2219,7 @@ struct Strip {
     int current = 0;
     hipStream_t compute = nullptr, comm_stream = nullptr;
     std::vector<hipStream_t> band; // the boundary bands' stream (highest priority), created when first needed
+    hipStream_t side = nullptr;    // the lower of two sub-strips with a moving boundary (ststhip_strip_advance), created when first needed
     ststhip_domain dom;        // geometry of the buffers (in words for the packed Game of Life)
     std::uint64_t n_launches = 0, n_exchanges = 0;
     // a block of a 2-D decomposition (ststhip_block_create): a column range and ghost columns as well
@@ -2421,6 +2423,10 @@ int ststhip_strip_destroy(ststhip_strip strip) {
         (void)hipStreamSynchronize(lane);
         (void)hipStreamDestroy(lane);
     }
+    if (st->side) {
+        (void)hipStreamSynchronize(st->side);
+        (void)hipStreamDestroy(st->side);
+    }
     for (auto &set : st->planes)
         for (void *plane : set)
             if (plane)
@@ -2559,7 +2565,32 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
         }
         band = st->band[0];
     }
-    g_launch_concurrency = 1;
+    // Two sub-strips with a moving boundary (as the pass driver's strips, ststhip_run_passes): the owned rows are swept
+    // as an upper and a lower launch per pass, on two streams; their common boundary moves up by the larger of this
+    // launch's ghost rows and the ones of the launch before, so the upper sub-strip's launches never wait for the lower
+    // one's and two launches are in flight -- a launch of a thin strip is too small to fill the chip on its own
+    // (2048 x 16384 cells: +15 % for the same cells as two strips, profiles/r04_skewed_strips.txt).  The boundary bands
+    // at the strip's ends and the exchange stay as they are; the boundary keeps moving across the groups of launches.
+    hipStream_t lane_low = nullptr;
+    std::uint64_t sub_span = 0;
+    {
+        for (std::size_t i = 0; i < depths.size(); i++)
+            sub_span += std::uint64_t(std::max(depths[i], i ? depths[i - 1] : 0u)) * hpg;
+        sub_span = std::min<std::uint64_t>(sub_span, (b - a) / 4);
+        const int wanted = opt().strip_substrips < 0
+                               ? suggest_row_strips(b - a, st->width, d.strip_width, st->g_max, depths.size())
+                               : opt().strip_substrips;
+        const bool usable = wanted >= 2 && opt().skewed_strips != 0 && depths.size() >= 2 && sub_span >= 2 * st->g_max &&
+                            (b - a) >= 2 * (st->ghost + 2 * st->g_max) + 2 * sub_span + 64;
+        if (usable) {
+            if (!st->side && hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking) != hipSuccess)
+                return hip_fail(hipErrorUnknown, "hipStreamCreateWithFlags");
+            lane_low = st->side;
+        }
+    }
+    std::uint64_t sub_offset = 0, sub_g_before = 0; // how far below its highest place the boundary is
+    hipEvent_t upper_done = nullptr, lower_done = nullptr;
+    g_launch_concurrency = lane_low ? 2 : 1;
 
     // one device table of time-dependent values for the whole call, as in ststhip_run_passes
     void *tdv_table = nullptr;
@@ -2587,6 +2618,8 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     wait(st->comm_stream, begin);
     if (band)
         wait(band, begin);
+    if (lane_low)
+        wait(lane_low, begin);
     hipEvent_t ghosts_ready = nullptr;
     if (st->n_ranks > 1 && rc == STSTHIP_OK) {
         rc = strip_exchange(*st, st->current, group_depth(0));
@@ -2596,6 +2629,8 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     for (std::size_t first = 0; first < depths.size() && rc == STSTHIP_OK; first += m) {
         const std::size_t last = std::min(first + m, depths.size()) - 1;
         wait(lane, ghosts_ready); // the group's first launch reads the ghost rows of this group
+        if (lane_low)
+            wait(lane_low, ghosts_ready);
         std::uint64_t widen = group_depth(first); // E_(j-1): how far beyond the owned rows the launch's input is valid
         for (std::size_t i = first; i <= last && rc == STSTHIP_OK; i++) {
             const std::uint32_t depth = depths[i];
@@ -2610,12 +2645,39 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
                     st->n_launches++;
                 }
             };
+            // rows [r0, r1) as one launch, or as the two sub-strips' launches
+            auto sweep_rows = [&](std::uint64_t r0, std::uint64_t r1) {
+                if (!lane_low) {
+                    sweep(r0, r1, lane);
+                    return;
+                }
+                const std::uint64_t shift = std::max<std::uint64_t>(depth * hpg, sub_g_before);
+                bool restart = false;
+                if (sub_offset + shift > sub_span) {
+                    sub_offset = 0;
+                    restart = true;
+                } else {
+                    sub_offset += shift;
+                }
+                sub_g_before = depth * hpg;
+                const std::uint64_t boundary = std::min(std::max((a + b) / 2 + sub_span / 2 - sub_offset, r0), r1);
+                if (restart)
+                    wait(lane, lower_done);
+                sweep(r0, boundary, lane);
+                hipEvent_t upper = record(lane);
+                wait(lane_low, upper_done);
+                sweep(boundary, r1, lane_low);
+                lower_done = record(lane_low);
+                upper_done = upper;
+            };
             const bool feeds_exchange = i == last && last + 1 < depths.size() && (has_up || has_down);
             if (feeds_exchange) {
                 const std::uint64_t next = group_depth(last + 1);
                 const std::uint64_t top_end = has_up ? a + next : a;
                 const std::uint64_t bot_begin = has_down ? b - next : b;
                 wait(band, record(lane)); // the bands read what the previous launch left (and what `lane` waited for)
+                if (lane_low)
+                    wait(band, record(lane_low));
                 if (has_up && has_down && top_end < bot_begin) {
                     // both bands as one launch with a hole where the interior is: one band latency in front of the exchange
                     g_row_hole_begin = top_end;
@@ -2632,10 +2694,12 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
                     rc = strip_exchange(*st, st->current ^ 1, next);
                     ghosts_ready = record(st->comm_stream);
                 }
-                sweep(top_end, bot_begin, lane);
+                sweep_rows(top_end, bot_begin);
                 wait(lane, banded); // the next launch reads the bands' rows
+                if (lane_low)
+                    wait(lane_low, banded);
             } else {
-                sweep(lo, hi, lane);
+                sweep_rows(lo, hi);
             }
             st->current ^= 1;
             iteration += depth;
@@ -2646,7 +2710,10 @@ int ststhip_strip_advance(ststhip_strip strip, uint64_t iteration_offset, uint64
     // the compute stream is the one callers synchronise with
     if (band)
         wait(lane, record(band));
+    if (lane_low)
+        wait(lane, record(lane_low));
     wait(lane, record(st->comm_stream));
+    g_launch_concurrency = 1;
     if (rc == STSTHIP_OK && blocking) {
         hipError_t err = hipStreamSynchronize(lane);
         if (err != hipSuccess)

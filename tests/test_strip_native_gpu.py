@@ -565,3 +565,41 @@ def test_block_driver_over_rccl_loopback(gpu, oracle):
         want = oracle.jacobi("Jacobi5General", coef, np.tile(grid, (3, 3)), 53, halo=halo, n_threads=8)[R:2 * R, Wc:2 * Wc]
         assert np.array_equal(bits(got), bits(want)), f"jacobi {coef[0]}"
     capi.comm_destroy(comm)
+
+
+@pytest.mark.parametrize("every", ["0", "2"])
+def test_strip_as_two_substrips_with_a_moving_boundary(gpu, oracle, monkeypatch, every):
+    """The strip driver sweeps a tall enough strip as an upper and a lower launch per pass whose common boundary moves up
+    by a launch's ghost rows (two launches in flight; ststhip_options::strip_substrips, here forced): the middle strip of
+    three over the RCCL loopback, 600 generations in two calls -- more than the boundary's span, so it starts over in the
+    middle of a call -- against the oracle on three stacked copies, and against the same strip swept as one launch per
+    pass.  Both Jacobi kernels; the launch counters show that two sub-strips ran."""
+    from stencilstream_amd import capi
+
+    monkeypatch.setenv("STSTHIP_EXCHANGE_EVERY", every)
+    capi.init(0)
+    comm = _loopback_comm()
+    R, W = 1536, 640
+    rng = np.random.default_rng(1536)
+    grid = rng.random((R, W), dtype=np.float32)
+    for coef, halo in (([0.2, 0.21, 0.19, 0.22, 0.18], 0.25), ([0.2] * 5, 0.0)):
+        p = capi.JacobiParams()
+        for i, c in enumerate(coef):
+            p.coef[i] = c
+        results, launches = [], []
+        for sub in ("2", "1"):
+            monkeypatch.setenv("STSTHIP_STRIP_SUBSTRIPS", sub)
+            capi.reload_options()
+            strip = capi.Strip("jacobi5general", p, np.float32(halo).tobytes(), 3 * R, W, 1, 3, comm=comm)
+            strip.upload(0, grid)
+            strip.warm_up()
+            strip.advance(0, 450)
+            strip.advance(450, 150, blocking=True)
+            results.append(strip.download(0, np.float32))
+            launches.append(strip.counters()[0])
+            strip.close()
+        assert launches[0] > 1.5 * launches[1], launches  # two launches per pass (and the bands) against one
+        want = oracle.jacobi("Jacobi5General", coef, np.tile(grid, (3, 1)), 600, halo=halo, n_threads=8)[R:2 * R]
+        assert np.array_equal(bits(results[0]), bits(want)), f"two sub-strips, coefficients {coef[0]}"
+        assert np.array_equal(bits(results[1]), bits(want)), f"one launch per pass, coefficients {coef[0]}"
+    capi.comm_destroy(comm)
