@@ -1698,6 +1698,9 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
                         break;
                     // (the shallower depth has to win by 2 %: a tie keeps the plan that is already laid out)
                     const bool take_alt = ms_alt < 0.98f * ms_deep;
+                    if (std::getenv("STSTHIP_TRACE_STREAM"))
+                        std::fprintf(stderr, "[ststhip] depth probe: 2 launches of %u generations %.3f ms, %u of %u %.3f ms -> %u\n",
+                                     deep, ms_deep, 2 * (deep / alt), alt, ms_alt, take_alt ? alt : deep);
                     if (take_alt) {
                         depths.resize(probe_passes);
                         depths.insert(depths.end(), rest_alt.begin(), rest_alt.end());
