@@ -1112,6 +1112,16 @@ inline int pick_chunk_rows(int out_rows, unsigned n_strips, int overhead_rows, i
         if (kernel_rule)
             *kernel_rule = true;
     }
+    // A launch beside another one that would fill less than two thirds of a residency round: the model above (units queue
+    // for slots) does not hold -- every unit runs at once, the launch takes as long as one unit, so shorter chunks are
+    // faster until the units fill the slots.  Measured (profiles/r04_thin_strips.txt, r04_skewed_strips.txt): a rank's
+    // 2048-row strip as two sub-strips 4264 -> 4412 (116 rows by the model, 64 by this), the pass driver's two strips at
+    // 6144^2 4664 -> 4871, general coefficients at 4096^2 2086 -> 2221; from 0.72 of a round on (8192^2) it loses 2 %.
+    if (side_by_side > 1 && double(chunks) * n_strips < 0.65 * slots) {
+        const long filled = long(0.93 * slots / double(std::max(1u, n_strips)));
+        const long least_rows = std::max<long>(16, long(overhead) * 3 / 2); // (not below one and a half warm-ups of useful rows)
+        chunks = std::max<long>(chunks, std::min<long>(filled, std::max<long>(1, long(out_rows) / least_rows)));
+    }
     // snap to a whole number of residency rounds (just below it) when that is a small change:
     // a launch of k*S + a few units pays for a nearly empty extra round
     const double rounds = double(chunks) * n_strips / slots;

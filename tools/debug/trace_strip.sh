@@ -10,7 +10,7 @@ import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/t/*/*kernel_trace.csv")[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size_X") or r.get("Grid_Size")), r["Kernel_Name"][:60]) for r in csv.DictReader(open(f)) if "sweep_kernel" in r["Kernel_Name"]]
 rows.sort()
-rows = rows[-78 * 2:]          # the last two steps
+rows = rows[-141 * 2:]         # the last two steps (141 launches each with two sub-strips)
 shapes = collections.Counter(g for _, _, g, _ in rows)
 big = max(shapes, key=lambda g: (shapes[g], g))
 print("launch shapes", dict(shapes))
@@ -25,4 +25,14 @@ for s, e, g, _ in rows[1:]:
     cur_e = max(cur_e, e)
 span = (rows[-1][1] - rows[0][0]) / 1e3
 print(f"span {span:.1f} us for {len(rows)} launches; idle gaps: n={len(gaps)} sum {sum(gaps):.1f} us mean {sum(gaps)/max(len(gaps),1):.2f} us max {max(gaps):.1f}")
+PY
+python3 - "$OUT" <<'PY'
+# one group of launches in time order: start, end, rows (grid), stream
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/t/*/*kernel_trace.csv")[0]
+rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Grid_Size_X"]), r["Stream_Id"]) for r in csv.DictReader(open(f)) if "sweep_kernel" in r["Kernel_Name"])
+rows = rows[-141:]
+t0 = rows[40][0]
+for s, e, g, st in rows[40:62]:
+    print(f"  {(s - t0) / 1e3:8.1f} -> {(e - t0) / 1e3:8.1f} us  {(e - s) / 1e3:6.1f} us  grid {g:7d}  stream {st}")
 PY
