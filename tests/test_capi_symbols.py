@@ -42,6 +42,15 @@ def test_options_come_from_the_environment_once(built_lib, monkeypatch):
     capi.reload_options()
     o = capi.options()
     assert (o.narrow_form_kcells, o.n_taper, o.skip_constant_stores, o.host_cache_mib) == (6000, -1, 1, 4096)
+    # the knobs of ABI 6, at the end of the struct: upload in row blocks, strips with moving boundaries, sub-strips by rule
+    assert (o.stream_upload, o.upload_block_mib, o.skewed_strips, o.strip_substrips) == (1, 0, 1, -1)
+    monkeypatch.setenv("STSTHIP_STRIP_SUBSTRIPS", "2")
+    monkeypatch.setenv("STSTHIP_UPLOAD_BLOCK_MIB", "5")
+    capi.reload_options()
+    assert (capi.options().strip_substrips, capi.options().upload_block_mib) == (2, 5)
+    monkeypatch.delenv("STSTHIP_STRIP_SUBSTRIPS")
+    monkeypatch.delenv("STSTHIP_UPLOAD_BLOCK_MIB")
+    capi.reload_options()
     monkeypatch.setenv("STSTHIP_CHUNK_ROWS", "77")
     monkeypatch.setenv("STSTHIP_TAPER", "150:2,50:4")
     monkeypatch.setenv("STSTHIP_EXCHANGE_EVERY", "3")
