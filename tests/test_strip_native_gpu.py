@@ -577,6 +577,7 @@ def test_strip_as_two_substrips_with_a_moving_boundary(gpu, oracle, monkeypatch,
     from stencilstream_amd import capi
 
     monkeypatch.setenv("STSTHIP_EXCHANGE_EVERY", every)
+    monkeypatch.setenv("STSTHIP_SKEWED_STRIPS", "1")  # (the sub-strips are the strips' moving boundary inside a rank)
     capi.init(0)
     comm = _loopback_comm()
     R, W = 1536, 640
