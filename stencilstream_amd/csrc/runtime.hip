@@ -1485,7 +1485,7 @@ int ststhip_run_passes(ststhip_sweep_fn sweep, void *ctx, const ststhip_sweep_de
             std::vector<std::uint64_t> frontier(stream_limit, 0);
             // How deep a column goes: as deep as it takes to keep the chip busy until the next block is there -- and a
             // little busier: a tile of one block's rows cannot fill the chip on its own (a 2048 x 16384 tile of the
-            // Jacobi example runs at 46 % of the whole grid's rate), two columns side by side do better, so the aim is ONE
+            // Jacobi example runs at 57 % of the whole grid's rate), two columns side by side do better, so the aim is ONE
             // or two earlier columns still running when a block arrives.  None: the chip has idled, and the column
             // before is timed against the blocks' arrival; three or more: the chip is behind, the next column goes
             // less deep (passes that are begun are completed by the last column whatever the later columns did).
