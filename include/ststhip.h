@@ -314,9 +314,11 @@ int ststhip_app_run(const char *app, const void *tf_params, const void *halo_cel
 /* The pass driver behind ststhip_app_run and stencil::hip::StencilUpdate: splits n_iterations into
  * launches of the compiled blocking depths, ping-pongs between `dst` and pooled scratch planes so
  * that the last pass lands in `dst` (`src` is never written), and -- for tall grids -- advances
- * several row strips on separate streams coupled only through their boundary bands, so that the
- * tail of one launch overlaps with the next launches.  `sweep` performs one launch (for C++
- * transition functions it is instantiated in the user's translation unit). */
+ * two row strips on separate streams, so that the tail of one launch overlaps with the next
+ * launches: strips whose common boundary moves up by a launch's ghost rows from pass to pass
+ * (ststhip_options::skewed_strips; the upper strip then never waits for the lower one), or fixed
+ * strips coupled through boundary bands.  `sweep` performs one launch (for C++ transition
+ * functions it is instantiated in the user's translation unit). */
 typedef int (*ststhip_sweep_fn)(void *ctx, const ststhip_domain *dom, const void *const *src,
                                 void *const *dst, uint64_t out_row_begin, uint64_t out_row_end,
                                 uint64_t iteration, uint32_t n_generations, ststhip_stream stream);
