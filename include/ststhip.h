@@ -452,7 +452,7 @@ int ststhip_comm_exchange_columns(ststhip_comm comm, int n_planes, const void *c
  * The grid is cut into n_ranks strips of consecutive rows; every process owns one strip on its GPU and keeps it,
  * with ghost rows, in two buffer sets inside the library.  ststhip_strip_advance() is cuda::StencilUpdate::operator()
  * for the whole distributed grid.  Its launches go in groups of m = STSTHIP_EXCHANGE_EVERY (default: 4 for strips
- * thinner than 4096 rows, else 2) with ONE exchange of m*T*radius*n_subiterations ghost rows per group (RCCL
+ * of up to 4096 rows, else 2) with ONE exchange of m*T*radius*n_subiterations ghost rows per group (RCCL
  * send/recv with the two neighbours over xGMI on a second stream, no collective): inside a group every launch
  * produces the owned rows widened by the ghost depth the rest of the group still needs; the last launch of a group
  * sweeps the rows next to the neighbours first (one band launch), hands them to the exchange for the next group, and

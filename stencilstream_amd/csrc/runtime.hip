@@ -2296,7 +2296,7 @@ int finish_strip(Strip *st, const ststhip_domain *dom, ststhip_strip *strip) {
     // Gcell/s per GPU at 1 / 2 / 4 launches per exchange)
     st->exchange_every = 1;
     if (st->n_ranks > 1) {
-        int every = opt().exchange_every > 0 ? std::min(opt().exchange_every, 16) : (thinnest < 4096 ? 4 : 2);
+        int every = opt().exchange_every > 0 ? std::min(opt().exchange_every, 16) : (thinnest <= 4096 ? 4 : 2);
         while (every > 1 && thinnest < 4 * st->g_max * std::uint64_t(every))
             every--;
         st->exchange_every = every;
